@@ -1,0 +1,170 @@
+"""Host-side mirror of the reference's inpainter class, backed by the HIP engine.
+
+Mirrors /root/reference/src/criminisi_inpainter.py: class name, constructor signature (:18),
+public attributes (:19-38), ``inpaint()`` (:40-88) with its validation error (:90-92) and its
+``verbose`` / ``show_progress`` side effects (:55-57,:67-69,:76-77,:85-87).  All arithmetic runs
+on the GPU through libcriminisi_hip.so; there is no CPU path.
+"""
+import os
+import time
+
+import numpy as np
+
+import crim_hip_capi as capi
+
+
+def _write_png(path, bgr):
+    """show_progress frame dump (criminisi_inpainter.py:56-57 uses cv2.imwrite on the BGR
+    array); OpenCV is used when the host has it, Pillow otherwise."""
+    try:
+        import cv2  # noqa: F401  (present on machines that run the full reference pipeline)
+        cv2.imwrite(path, bgr)
+        return
+    except ImportError:
+        pass
+    from PIL import Image
+    Image.fromarray(np.ascontiguousarray(bgr[:, :, ::-1])).save(path)
+
+
+class Criminisi_Inpainter():
+    '''
+    Criminisi (2004) exemplar-based inpainting on an AMD MI355X.
+
+    Requires binary mask of missing region, same size as image.
+        Pixels values: 1 for missing, 0 for known region.
+    '''
+
+    def __init__(self, image, mask, patch_size=9, verbose=False, show_progress=False, device=0):
+        self.image = image
+        self.mask = mask.round()
+        self.patch_size = patch_size
+        self.verbose = verbose
+        self.show_progress = show_progress
+        self.device = device
+
+        self.iheight, self.iwidth = self.image.shape[:2]
+        self.working_image = np.copy(self.image)
+        self.working_mask = np.copy(self.mask)
+        self.confidence = (1.0 - self.mask)
+        self._front = np.zeros([self.iheight, self.iwidth])
+        self._data = np.zeros([self.iheight, self.iwidth])
+        self._priority = np.zeros([self.iheight, self.iwidth])
+        self._engine = None
+        self._fields_stale = False
+        self.iterations = 0
+
+    # front / data / priority (criminisi_inpainter.py:31,37,38) are materialised on demand: the
+    # fill loop never needs them as full frames.  After inpaint() they hold what the next
+    # iteration would compute from the final state.
+    def _refresh_fields(self):
+        if self._fields_stale and self._engine is not None:
+            f, d, p = self._engine.peek_fields(0)
+            self._front, self._data, self._priority = f, d, p
+            self._fields_stale = False
+
+    @property
+    def front(self):
+        self._refresh_fields()
+        return self._front
+
+    @property
+    def data(self):
+        self._refresh_fields()
+        return self._data
+
+    @property
+    def priority(self):
+        self._refresh_fields()
+        return self._priority
+
+    def inpaint(self):
+        '''
+        Compute the new image and return it.
+        '''
+        self._validate_inputs()
+        img = np.asarray(self.image)
+        if img.ndim != 3 or img.shape[2] != 3 or img.dtype != np.uint8:
+            raise ValueError('image must be a uint8 array of shape (H, W, 3) in BGR order')
+        mask_u8 = (np.asarray(self.mask) != 0).astype(np.uint8)
+
+        start_time = time.time()
+        total = int(np.sum(self.mask))
+        eng = capi.Engine(self.iheight, self.iwidth, self.patch_size, batch=1, device=self.device)
+        self._engine = eng
+        eng.upload(img, mask_u8)
+
+        if self.verbose or self.show_progress:
+            # Per-iteration side effects need the host in the loop: one iteration per call.
+            c = 0
+            while True:
+                if self.show_progress:
+                    frame, _, _ = eng.download()
+                    _write_png('results/working_image_' + str(c) + '.png', frame[0])
+                find_start_time = time.time()
+                _, remaining = eng.run(max_iters=1)
+                if self.verbose:
+                    print('Time to find best: %.2f seconds' % (time.time() - find_start_time))
+                    print('%d of %d completed' % (total - remaining, total))
+                if remaining == 0:
+                    break
+                c += 1
+        else:
+            eng.run()
+
+        out, conf, msk = eng.download(want_conf=True, want_mask=True)
+        self.working_image = out[0]
+        self.confidence = conf[0]
+        self.working_mask = msk[0].astype(self.working_mask.dtype)
+        self.iterations = eng.iterations(0)
+        self._fields_stale = True
+
+        if self.verbose:
+            print('Inpainting took %.2f seconds to complete' % (time.time() - start_time))
+        return self.working_image
+
+    def trace(self):
+        """Per-iteration (target, source, cost, remaining) records of the last inpaint()."""
+        if self._engine is None:
+            raise RuntimeError('inpaint() has not been run')
+        return self._engine.trace(0)
+
+    def _validate_inputs(self):
+        if self.image.shape[:2] != self.mask.shape:
+            raise AttributeError('mask and image must be of the same size')
+
+    def __del__(self):
+        eng = getattr(self, '_engine', None)
+        if eng is not None:
+            eng.close()
+
+
+# north-star spelling
+CriminisiInpainter = Criminisi_Inpainter
+
+
+def inpaint_many(images, masks, patch_size=9, device=0, batch=None):
+    """Inpaints a list/array of same-shaped images as lock-step batches on one GPU: the loop of
+    /root/reference/scripts/main.py:44-58 around Criminisi_Inpainter(...).inpaint(), without the
+    per-image launch latency.  Returns uint8 [n,H,W,3]."""
+    images = np.ascontiguousarray(images, dtype=np.uint8)
+    masks = np.ascontiguousarray(np.asarray(masks) != 0, dtype=np.uint8)
+    n, H, W = masks.shape
+    if images.shape != (n, H, W, 3):
+        raise AttributeError('mask and image must be of the same size')
+    batch = n if batch is None else max(1, min(int(batch), n))
+    out = np.empty_like(images)
+    with capi.Engine(H, W, patch_size, batch=batch, device=device) as eng:
+        for lo in range(0, n, batch):
+            hi = min(lo + batch, n)
+            cnt = hi - lo
+            if cnt < batch:
+                # pad the last batch with empty masks (finish after one no-op iteration)
+                pad_i = np.zeros((batch - cnt, H, W, 3), np.uint8)
+                pad_m = np.zeros((batch - cnt, H, W), np.uint8)
+                eng.upload(np.concatenate([images[lo:hi], pad_i]), np.concatenate([masks[lo:hi], pad_m]))
+            else:
+                eng.upload(images[lo:hi], masks[lo:hi])
+            eng.run()
+            res, _, _ = eng.download(0, cnt)
+            out[lo:hi] = res
+    return out

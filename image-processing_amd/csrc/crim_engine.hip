@@ -1,0 +1,626 @@
+// Host side of libcriminisi_hip.so: device memory, upload/download, hipGraph-driven fill loop
+// and the C ABI declared in include/criminisi_hip.h.  Replaces the Python driver loop of
+// Criminisi_Inpainter.inpaint() (/root/reference/src/criminisi_inpainter.py:40-88).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <vector>
+
+#include "crim_kernels.h"
+
+// ------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(CRIM_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                               \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------
+// BGR -> Lab tables (OpenCV's integer RGB2Lab_b path, restated; the reference reaches it
+// through cv2.cvtColor(..., COLOR_BGR2LAB), criminisi_inpainter.py:225)
+// ------------------------------------------------------------------------------------------
+
+namespace {
+
+struct LabTables {
+    uint16_t gamma[256];
+    uint16_t cbrt_[3072];
+    int32_t coef[9];
+};
+
+// cvRound: nearest, ties to even
+int round_half_even(double v) { return (int)nearbyint(v); }
+
+// OpenCV's cubeRoot(): exponent split, then a quartic rational polynomial in double, rounded to
+// float.  Restated because the table entries are cvRound(32768 * this), not a true cbrt.
+float opencv_cbrt(float value) {
+    if (value == 0.0f) return 0.0f;
+    uint32_t bits;
+    memcpy(&bits, &value, 4);
+    const uint32_t ix = bits & 0x7fffffffu;
+    int ex = (int)(ix >> 23) - 127;
+    int shx = ex % 3;
+    shx -= shx >= 0 ? 3 : 0;
+    ex = (ex - shx) / 3;
+    const uint32_t frbits = (ix & ((1u << 23) - 1u)) | ((uint32_t)(shx + 127) << 23);
+    float frf;
+    memcpy(&frf, &frbits, 4);
+    const double fr = frf;
+    const double num = ((((45.2548339756803022511987494 * fr + 192.2798368355061050458134625) * fr +
+                          119.1654824285581628956914143) * fr + 13.43250139086239872172837314) * fr +
+                        0.1636161226585754240958355063);
+    const double den = ((((14.80884093219134573786480845 * fr + 151.9714051044435648658557668) * fr +
+                          168.5254414101568283957668343) * fr + 33.9905941350215598754191872) * fr +
+                        1.0);
+    float y = (float)(num / den);
+    uint32_t yb;
+    memcpy(&yb, &y, 4);
+    yb += (uint32_t)(ex << 23);
+    memcpy(&y, &yb, 4);
+    return y;
+}
+
+void build_lab_tables(LabTables& t) {
+    const float f255 = 255.0f;
+    const float int_scale = 2040.0f;  // 255 * 2^3
+    const double one_plus_shift = 1.0 + 11.0 / 200.0;
+    for (int i = 0; i < 256; ++i) {
+        const float x = (float)i / f255;
+        const double xd = x;
+        double g;
+        if (xd <= 809.0 / 20000.0) g = xd / (323.0 / 25.0);
+        else g = pow((xd + 11.0 / 200.0) / one_plus_shift, 12.0 / 5.0);
+        const float gf = (float)g;
+        t.gamma[i] = (uint16_t)round_half_even((double)(int_scale * gf));
+    }
+    const float lthresh = 216.0f / 24389.0f;
+    const float lscale = 841.0f / 108.0f;
+    const float lbias = 16.0f / 116.0f;
+    const float cb_scale = 1.0f / (f255 * 8.0f);
+    for (int i = 0; i < 3072; ++i) {
+        const float x = cb_scale * (float)i;
+        const float y = x < lthresh ? fmaf(x, lscale, lbias) : opencv_cbrt(x);
+        t.cbrt_[i] = (uint16_t)round_half_even((double)(32768.0f * y));
+    }
+    static const double m[9] = {0.412453, 0.357580, 0.180423, 0.212671, 0.715160,
+                                0.072169, 0.019334, 0.119193, 0.950227};
+    static const double wp[3] = {0.950456, 1.0, 1.088754};
+    for (int i = 0; i < 3; ++i) {
+        t.coef[3 * i + 2] = round_half_even(4096.0 * m[3 * i + 0] / wp[i]);  // multiplies R
+        t.coef[3 * i + 1] = round_half_even(4096.0 * m[3 * i + 1] / wp[i]);  // multiplies G
+        t.coef[3 * i + 0] = round_half_even(4096.0 * m[3 * i + 2] / wp[i]);  // multiplies B
+    }
+}
+
+const LabTables& lab_tables() {
+    static LabTables t;
+    static bool built = false;
+    if (!built) {
+        build_lab_tables(t);
+        built = true;
+    }
+    return t;
+}
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// engine
+// ------------------------------------------------------------------------------------------
+
+struct GraphSet {
+    hipGraphExec_t exec = nullptr;
+    int iters = 0;
+};
+
+struct crim_engine {
+    int device = 0;
+    unsigned flags = 0;
+    int patch_size = 0;
+    Params prm;
+    hipStream_t stream = nullptr;
+    int* d_bbox = nullptr;          // [B][4] ymin, ymax, xmin, xmax of each uploaded mask
+    uint16_t* d_gamma = nullptr;
+    uint16_t* d_cbrt = nullptr;
+    ImgState* h_state = nullptr;    // pinned mirror of prm.st
+    std::vector<bool> uploaded;
+    bool prepared = false;          // scan window, trace buffer and graphs match the uploads
+    std::vector<GraphSet> graphs;
+    // profile accumulators
+    std::vector<hipEvent_t> ev;     // pairs
+    int ev_used = 0;
+    std::vector<double> ev_evals;
+    double prof_ms = 0.0, prof_evals = 0.0;
+    long prof_launches = 0;
+    void* d_peek = nullptr;         // scratch for crim_peek_fields
+};
+
+static void free_graphs(crim_engine* h) {
+    for (auto& g : h->graphs)
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    h->graphs.clear();
+}
+
+static void launch_search(crim_engine* h, hipStream_t s) {
+    const Params& p = h->prm;
+    dim3 grid(p.snx, p.sny, p.B), block(256);
+    if (p.generic) {
+        hipLaunchKernelGGL(k_search_generic, grid, block, 0, s, p);
+        return;
+    }
+    switch (p.P) {
+        case 3: hipLaunchKernelGGL(k_search<3>, grid, block, 0, s, p); break;
+        case 5: hipLaunchKernelGGL(k_search<5>, grid, block, 0, s, p); break;
+        case 7: hipLaunchKernelGGL(k_search<7>, grid, block, 0, s, p); break;
+        case 9: hipLaunchKernelGGL(k_search<9>, grid, block, 0, s, p); break;
+        case 11: hipLaunchKernelGGL(k_search<11>, grid, block, 0, s, p); break;
+        case 13: hipLaunchKernelGGL(k_search<13>, grid, block, 0, s, p); break;
+        case 15: hipLaunchKernelGGL(k_search<15>, grid, block, 0, s, p); break;
+        default: hipLaunchKernelGGL(k_search_generic, grid, block, 0, s, p); break;
+    }
+}
+
+static bool has_fast_search(int P) { return P >= 3 && P <= 15 && (P & 1); }
+
+// One iteration of criminisi_inpainter.py:51-83 as four dependent launches.
+static void launch_iteration(crim_engine* h, hipStream_t s, bool profile) {
+    const Params& p = h->prm;
+    hipLaunchKernelGGL(k_priority, dim3(p.ptnx, p.ptny, p.B), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(k_select, dim3(p.B), dim3(256), 0, s, p);
+    if (profile) (void)hipEventRecord(h->ev[2 * h->ev_used], s);
+    launch_search(h, s);
+    if (profile) (void)hipEventRecord(h->ev[2 * h->ev_used + 1], s);
+    hipLaunchKernelGGL(k_update, dim3(p.B), dim3(256), 0, s, p);
+}
+
+static int build_graph(crim_engine* h, int iters, GraphSet* out) {
+    hipGraph_t graph = nullptr;
+    HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    for (int i = 0; i < iters; ++i) launch_iteration(h, h->stream, false);
+    HIP_TRY(hipStreamEndCapture(h->stream, &graph));
+    hipGraphExec_t exec = nullptr;
+    hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) return fail(CRIM_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+    out->exec = exec;
+    out->iters = iters;
+    return CRIM_OK;
+}
+
+extern "C" int crim_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" const char* crim_last_error(void) { return g_err; }
+
+extern "C" int crim_lab_tables(uint16_t* gamma256, uint16_t* cbrt3072, int32_t* coeffs9) {
+    const LabTables& t = lab_tables();
+    if (gamma256) memcpy(gamma256, t.gamma, sizeof(t.gamma));
+    if (cbrt3072) memcpy(cbrt3072, t.cbrt_, sizeof(t.cbrt_));
+    if (coeffs9) memcpy(coeffs9, t.coef, sizeof(t.coef));
+    return CRIM_OK;
+}
+
+extern "C" void crim_destroy(crim_t* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    free_graphs(h);
+    for (auto e : h->ev) (void)hipEventDestroy(e);
+    Params& p = h->prm;
+    void* bufs[] = {p.bgr, p.planes, p.mask, p.grey, p.grad, p.conf, p.invalid, p.tilecnt, p.st,
+                    p.desc, p.plist, p.slist, p.trace, h->d_bbox, h->d_gamma, h->d_cbrt, h->d_peek};
+    for (void* q : bufs)
+        if (q) (void)hipFree(q);
+    if (h->h_state) (void)hipHostFree(h->h_state);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" int crim_create_batch(int batch, int H, int W, int patch_size, int device,
+                                 unsigned flags, crim_t** out) {
+    if (!out) return fail(CRIM_ERR_ARG, "crim_create: out is null");
+    *out = nullptr;
+    if (batch < 1 || H < 1 || W < 1) return fail(CRIM_ERR_ARG, "crim_create: bad shape %d x %d x %d", batch, H, W);
+    if (patch_size < 1 || patch_size > CRIM_MAX_PATCH)
+        return fail(CRIM_ERR_ARG, "crim_create: patch_size %d outside 1..%d", patch_size, CRIM_MAX_PATCH);
+    if ((double)H * W > 2.0e9 / 4) return fail(CRIM_ERR_ARG, "crim_create: image too large");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(CRIM_ERR_ARG, "crim_create: device %d of %d", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    crim_engine* h = new (std::nothrow) crim_engine();
+    if (!h) return fail(CRIM_ERR_NOMEM, "crim_create: out of host memory");
+    h->device = device;
+    h->flags = flags;
+    if (flags & CRIM_FLAG_PROFILE) h->flags |= CRIM_FLAG_EAGER;
+    h->patch_size = patch_size;
+    Params& p = h->prm;
+    memset(&p, 0, sizeof(p));
+    p.B = batch; p.H = H; p.W = W;
+    p.half = (patch_size - 1) / 2;
+    p.P = 2 * p.half + 1;
+    p.psq = patch_size * patch_size;
+    p.ND = (p.P + 6) / 4;
+    p.Wp = round_up(W + 16, 16);
+    p.Wi = round_up(W, 4) + 4;
+    p.tnx = (W + CRIM_TILE - 1) / CRIM_TILE;
+    p.tny = (H + CRIM_TILE - 1) / CRIM_TILE;
+    p.ptx0 = 0; p.pty0 = 0; p.ptnx = p.tnx; p.ptny = p.tny;
+    // the candidate grid is largest for the most clipped patch: (H - half) x (W - half)
+    p.snx = (std::max(W - p.half, 1) + SB_W - 1) / SB_W;
+    p.sny = (std::max(H - p.half, 1) + SB_H - 1) / SB_H;
+    p.generic = ((flags & CRIM_FLAG_GENERIC_SEARCH) || !has_fast_search(p.P)) ? 1 : 0;
+    p.trace_cap = 0;
+    const size_t HW = (size_t)H * W, Bz = (size_t)batch;
+    const LabTables& t = lab_tables();
+    memcpy(p.coef, t.coef, sizeof(p.coef));
+    hipError_t e = hipSuccess;
+    auto alloc = [&](void** ptr, size_t bytes) {
+        if (e == hipSuccess) e = hipMalloc(ptr, bytes);
+    };
+    alloc((void**)&p.bgr, Bz * HW * 3);
+    alloc((void**)&p.planes, Bz * 5 * H * p.Wp);
+    alloc((void**)&p.mask, Bz * HW);
+    alloc((void**)&p.grey, Bz * HW);
+    alloc((void**)&p.grad, Bz * HW * sizeof(int));
+    alloc((void**)&p.conf, Bz * 2 * HW * sizeof(double));
+    alloc((void**)&p.invalid, Bz * H * p.Wi);
+    alloc((void**)&p.tilecnt, Bz * p.tnx * p.tny * sizeof(int));
+    alloc((void**)&p.st, Bz * sizeof(ImgState));
+    alloc((void**)&p.desc, Bz * sizeof(Desc));
+    alloc((void**)&p.plist, Bz * p.tnx * p.tny * sizeof(PEntry));
+    alloc((void**)&p.slist, Bz * p.snx * p.sny * sizeof(SEntry));
+    alloc((void**)&h->d_bbox, Bz * 4 * sizeof(int));
+    alloc((void**)&h->d_gamma, sizeof(t.gamma));
+    alloc((void**)&h->d_cbrt, sizeof(t.cbrt_));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_state, Bz * sizeof(ImgState), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMemcpy(h->d_gamma, t.gamma, sizeof(t.gamma), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(h->d_cbrt, t.cbrt_, sizeof(t.cbrt_), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(p.planes, 0, Bz * 5 * H * p.Wp);
+    if (e == hipSuccess) e = hipMemset(p.invalid, 1, Bz * H * p.Wi);
+    if (e == hipSuccess) e = hipMemset(p.st, 0, Bz * sizeof(ImgState));
+    if (e == hipSuccess) e = hipMemset(p.desc, 0, Bz * sizeof(Desc));
+    if (e != hipSuccess) {
+        const int code = fail(e == hipErrorOutOfMemory ? CRIM_ERR_NOMEM : CRIM_ERR_HIP,
+                              "crim_create: %s", hipGetErrorString(e));
+        crim_destroy(h);
+        return code;
+    }
+    p.gamma_tab = h->d_gamma;
+    p.cbrt_tab = h->d_cbrt;
+    h->uploaded.assign(batch, false);
+    if (h->flags & CRIM_FLAG_PROFILE) {
+        h->ev.resize(2 * 64);
+        h->ev_evals.resize(64);
+        for (auto& ev : h->ev) HIP_TRY(hipEventCreate(&ev));
+    }
+    *out = h;
+    return CRIM_OK;
+}
+
+extern "C" int crim_create(int H, int W, int patch_size, int device, unsigned flags, crim_t** out) {
+    return crim_create_batch(1, H, W, patch_size, device, flags, out);
+}
+
+// Derives every cached field of images [first, first+count) from prm.bgr / prm.mask.
+static int init_images(crim_engine* h, int first, int count) {
+    const Params& p = h->prm;
+    hipLaunchKernelGGL(k_init_state, dim3((count + 63) / 64), dim3(64), 0, h->stream, p, first, count, h->d_bbox);
+    dim3 grid(p.tnx, p.tny, count), block(256);
+    hipLaunchKernelGGL(k_init_pixels, grid, block, 0, h->stream, p, first, h->d_bbox);
+    hipLaunchKernelGGL(k_init_fields, grid, block, 0, h->stream, p, first);
+    HIP_TRY(hipGetLastError());
+    for (int i = 0; i < count; ++i) h->uploaded[first + i] = true;
+    h->prepared = false;
+    h->prof_ms = 0.0; h->prof_evals = 0.0; h->prof_launches = 0;
+    return CRIM_OK;
+}
+
+extern "C" int crim_upload_batch(crim_t* h, int first, int count, const uint8_t* bgr,
+                                 ptrdiff_t image_stride, ptrdiff_t row_stride, const uint8_t* mask,
+                                 ptrdiff_t mask_image_stride, ptrdiff_t mask_row_stride) {
+    if (!h || !bgr || !mask) return fail(CRIM_ERR_ARG, "crim_upload: null argument");
+    const Params& p = h->prm;
+    if (first < 0 || count < 1 || first + count > p.B)
+        return fail(CRIM_ERR_ARG, "crim_upload: images [%d,%d) outside batch of %d", first, first + count, p.B);
+    if (row_stride < (ptrdiff_t)p.W * 3 || mask_row_stride < (ptrdiff_t)p.W)
+        return fail(CRIM_ERR_ARG, "crim_upload: row stride smaller than a row");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t HW = (size_t)p.H * p.W;
+    for (int i = 0; i < count; ++i) {
+        HIP_TRY(hipMemcpy2DAsync(p.bgr + (size_t)(first + i) * HW * 3, (size_t)p.W * 3,
+                                 bgr + (ptrdiff_t)i * image_stride, (size_t)row_stride,
+                                 (size_t)p.W * 3, p.H, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpy2DAsync(p.mask + (size_t)(first + i) * HW, (size_t)p.W,
+                                 mask + (ptrdiff_t)i * mask_image_stride, (size_t)mask_row_stride,
+                                 (size_t)p.W, p.H, hipMemcpyHostToDevice, h->stream));
+    }
+    const int rc = init_images(h, first, count);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));   // the host buffers may be reused on return
+    return CRIM_OK;
+}
+
+extern "C" int crim_upload(crim_t* h, const uint8_t* bgr, ptrdiff_t row_stride, const uint8_t* mask,
+                           ptrdiff_t mask_row_stride) {
+    return crim_upload_batch(h, 0, 1, bgr, 0, row_stride, mask, 0, mask_row_stride);
+}
+
+extern "C" int crim_upload_device(crim_t* h, int first, int count, const void* d_bgr,
+                                  const void* d_mask) {
+    if (!h || !d_bgr || !d_mask) return fail(CRIM_ERR_ARG, "crim_upload_device: null argument");
+    const Params& p = h->prm;
+    if (first < 0 || count < 1 || first + count > p.B)
+        return fail(CRIM_ERR_ARG, "crim_upload_device: images [%d,%d) outside batch of %d", first, first + count, p.B);
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t HW = (size_t)p.H * p.W;
+    HIP_TRY(hipMemcpyAsync(p.bgr + (size_t)first * HW * 3, d_bgr, (size_t)count * HW * 3,
+                           hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(p.mask + (size_t)first * HW, d_mask, (size_t)count * HW,
+                           hipMemcpyDeviceToDevice, h->stream));
+    return init_images(h, first, count);
+}
+
+// Sizes the priority scan window and the trace buffer from what was uploaded, then (re)builds
+// the iteration graphs.
+static int prepare(crim_engine* h) {
+    Params& p = h->prm;
+    for (int i = 0; i < p.B; ++i)
+        if (!h->uploaded[i]) return fail(CRIM_ERR_STATE, "crim_run: image %d was never uploaded", i);
+    int bbox[4] = {0x7fffffff, -1, 0x7fffffff, -1};
+    std::vector<int> bb((size_t)p.B * 4);
+    HIP_TRY(hipMemcpyAsync(h->h_state, p.st, (size_t)p.B * sizeof(ImgState), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(bb.data(), h->d_bbox, bb.size() * sizeof(int), hipMemcpyDeviceToHost));
+    for (int i = 0; i < p.B; ++i) {
+        bbox[0] = std::min(bbox[0], bb[4 * i]); bbox[1] = std::max(bbox[1], bb[4 * i + 1]);
+        bbox[2] = std::min(bbox[2], bb[4 * i + 2]); bbox[3] = std::max(bbox[3], bb[4 * i + 3]);
+    }
+    Params q = p;
+    if (bbox[1] >= bbox[0] && bbox[3] >= bbox[2]) {
+        // front pixels lie within one pixel of a masked pixel
+        const int y0 = std::max(bbox[0] - 1, 0), y1 = std::min(bbox[1] + 1, p.H - 1);
+        const int x0 = std::max(bbox[2] - 1, 0), x1 = std::min(bbox[3] + 1, p.W - 1);
+        q.pty0 = y0 / CRIM_TILE; q.ptny = y1 / CRIM_TILE - q.pty0 + 1;
+        q.ptx0 = x0 / CRIM_TILE; q.ptnx = x1 / CRIM_TILE - q.ptx0 + 1;
+    } else {
+        q.ptx0 = q.pty0 = 0; q.ptnx = q.ptny = 1;
+    }
+    long need = 1;
+    for (int i = 0; i < p.B; ++i) need = std::max(need, (long)h->h_state[i].remaining + 1);
+    if (need > p.trace_cap || !p.trace) {
+        if (p.trace) HIP_TRY(hipFree(p.trace));
+        q.trace = nullptr;
+        p.trace = nullptr;
+        HIP_TRY(hipMalloc((void**)&q.trace, (size_t)p.B * need * sizeof(crim_iter_rec)));
+        q.trace_cap = need;
+    }
+    const bool changed = memcmp(&q, &p, sizeof(Params)) != 0;
+    p = q;
+    if (changed || h->graphs.empty()) {
+        free_graphs(h);
+        if (!(h->flags & CRIM_FLAG_EAGER)) {
+            static const int sizes[3] = {64, 8, 1};
+            for (int s : sizes) {
+                GraphSet g;
+                const int rc = build_graph(h, s, &g);
+                if (rc) return rc;
+                h->graphs.push_back(g);
+            }
+        }
+    }
+    h->prepared = true;
+    return CRIM_OK;
+}
+
+static int flush_profile(crim_engine* h) {
+    for (int i = 0; i < h->ev_used; ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventSynchronize(h->ev[2 * i + 1]));
+        HIP_TRY(hipEventElapsedTime(&ms, h->ev[2 * i], h->ev[2 * i + 1]));
+        h->prof_ms += ms;
+        h->prof_evals += h->ev_evals[i];
+        h->prof_launches += 1;
+    }
+    h->ev_used = 0;
+    return CRIM_OK;
+}
+
+extern "C" int crim_run(crim_t* h, long max_iters, long* iters_done, long* remaining) {
+    if (!h) return fail(CRIM_ERR_ARG, "crim_run: null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    if (!h->prepared) {
+        const int rc = prepare(h);
+        if (rc) return rc;
+    }
+    Params& p = h->prm;
+    const bool profile = (h->flags & CRIM_FLAG_PROFILE) != 0;
+    const bool eager = (h->flags & CRIM_FLAG_EAGER) != 0;
+    long done = 0;
+    int rc = CRIM_OK;
+    for (;;) {
+        HIP_TRY(hipMemcpyAsync(h->h_state, p.st, (size_t)p.B * sizeof(ImgState), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        long need = 0, live = 0;
+        for (int i = 0; i < p.B; ++i) {
+            const ImgState& s = h->h_state[i];
+            if (s.stalled) rc = CRIM_ERR_NO_PROGRESS;
+            if (!s.live) continue;
+            ++live;
+            // every iteration fills at most P*P pixels: a lower bound on what is still needed
+            const long lb = std::max(1L, ((long)s.remaining + p.P * p.P - 1) / (p.P * p.P));
+            need = std::max(need, lb);
+        }
+        if (rc || live == 0) break;
+        if (max_iters > 0) {
+            if (done >= max_iters) break;
+            need = std::min(need, max_iters - done);
+        }
+        if (profile) {
+            // one iteration per round so that the number of live images per launch is known
+            const double evals = (double)live * (double)std::max(p.H - p.P + 1, 0) * (double)std::max(p.W - p.P + 1, 0);
+            h->ev_evals[h->ev_used] = evals;
+            launch_iteration(h, h->stream, true);
+            ++h->ev_used;
+            if (h->ev_used == (int)h->ev_evals.size()) {
+                const int r2 = flush_profile(h);
+                if (r2) return r2;
+            }
+            done += 1;
+        } else if (eager) {
+            for (long i = 0; i < need; ++i) launch_iteration(h, h->stream, false);
+            done += need;
+        } else {
+            long left = need;
+            for (auto& g : h->graphs)
+                while (left >= g.iters) {
+                    HIP_TRY(hipGraphLaunch(g.exec, h->stream));
+                    left -= g.iters;
+                }
+            done += need;
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    if (profile) {
+        const int r2 = flush_profile(h);
+        if (r2) return r2;
+    }
+    long it = 0, rem = 0;
+    for (int i = 0; i < p.B; ++i) {
+        it = std::max(it, (long)h->h_state[i].iter);
+        rem += h->h_state[i].remaining;
+    }
+    if (iters_done) *iters_done = it;
+    if (remaining) *remaining = rem;
+    if (rc == CRIM_ERR_NO_PROGRESS)
+        return fail(rc, "crim_run: an iteration filled no pixel while %ld remain (the reference loop would not terminate)", rem);
+    return CRIM_OK;
+}
+
+extern "C" int crim_download_batch(crim_t* h, int first, int count, uint8_t* bgr_out,
+                                   double* conf_out, uint8_t* mask_out) {
+    if (!h) return fail(CRIM_ERR_ARG, "crim_download: null handle");
+    const Params& p = h->prm;
+    if (first < 0 || count < 1 || first + count > p.B)
+        return fail(CRIM_ERR_ARG, "crim_download: images [%d,%d) outside batch of %d", first, first + count, p.B);
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t HW = (size_t)p.H * p.W;
+    HIP_TRY(hipMemcpyAsync(h->h_state, p.st, (size_t)p.B * sizeof(ImgState), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (bgr_out)
+        HIP_TRY(hipMemcpyAsync(bgr_out, p.bgr + (size_t)first * HW * 3, (size_t)count * HW * 3,
+                               hipMemcpyDeviceToHost, h->stream));
+    if (mask_out)
+        HIP_TRY(hipMemcpyAsync(mask_out, p.mask + (size_t)first * HW, (size_t)count * HW,
+                               hipMemcpyDeviceToHost, h->stream));
+    if (conf_out)
+        for (int i = 0; i < count; ++i) {
+            const int cur = h->h_state[first + i].cur;
+            HIP_TRY(hipMemcpyAsync(conf_out + (size_t)i * HW,
+                                   p.conf + ((size_t)(first + i) * 2 + cur) * HW, HW * sizeof(double),
+                                   hipMemcpyDeviceToHost, h->stream));
+        }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return CRIM_OK;
+}
+
+extern "C" int crim_download(crim_t* h, uint8_t* bgr_out, double* conf_out, uint8_t* mask_out) {
+    return crim_download_batch(h, 0, 1, bgr_out, conf_out, mask_out);
+}
+
+extern "C" int crim_download_device(crim_t* h, int first, int count, void* d_bgr_out) {
+    if (!h || !d_bgr_out) return fail(CRIM_ERR_ARG, "crim_download_device: null argument");
+    const Params& p = h->prm;
+    if (first < 0 || count < 1 || first + count > p.B)
+        return fail(CRIM_ERR_ARG, "crim_download_device: images [%d,%d) outside batch of %d", first, first + count, p.B);
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t HW = (size_t)p.H * p.W;
+    HIP_TRY(hipMemcpyAsync(d_bgr_out, p.bgr + (size_t)first * HW * 3, (size_t)count * HW * 3,
+                           hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return CRIM_OK;
+}
+
+extern "C" int crim_iterations(crim_t* h, int index, long* n) {
+    if (!h || !n) return fail(CRIM_ERR_ARG, "crim_iterations: null argument");
+    const Params& p = h->prm;
+    if (index < 0 || index >= p.B) return fail(CRIM_ERR_ARG, "crim_iterations: index %d of %d", index, p.B);
+    HIP_TRY(hipSetDevice(h->device));
+    ImgState s;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(&s, p.st + index, sizeof(s), hipMemcpyDeviceToHost));
+    *n = s.iter;
+    return CRIM_OK;
+}
+
+extern "C" int crim_trace(crim_t* h, int index, crim_iter_rec* buf, long cap, long* n) {
+    if (!h || !n) return fail(CRIM_ERR_ARG, "crim_trace: null argument");
+    const Params& p = h->prm;
+    if (index < 0 || index >= p.B) return fail(CRIM_ERR_ARG, "crim_trace: index %d of %d", index, p.B);
+    long iters = 0;
+    const int rc = crim_iterations(h, index, &iters);
+    if (rc) return rc;
+    const long have = std::min(iters, p.trace_cap);
+    *n = have;
+    const long take = std::min(have, cap);
+    if (buf && take > 0)
+        HIP_TRY(hipMemcpy(buf, p.trace + (size_t)index * p.trace_cap, (size_t)take * sizeof(crim_iter_rec),
+                          hipMemcpyDeviceToHost));
+    return CRIM_OK;
+}
+
+extern "C" int crim_profile(crim_t* h, double* search_ms, long* search_launches, double* evals) {
+    if (!h) return fail(CRIM_ERR_ARG, "crim_profile: null handle");
+    if (!(h->flags & CRIM_FLAG_PROFILE)) return fail(CRIM_ERR_STATE, "crim_profile: engine was not created with CRIM_FLAG_PROFILE");
+    if (search_ms) *search_ms = h->prof_ms;
+    if (search_launches) *search_launches = h->prof_launches;
+    if (evals) *evals = h->prof_evals;
+    return CRIM_OK;
+}
+
+extern "C" int crim_peek_fields(crim_t* h, int index, uint8_t* front_out, double* data_out,
+                                double* priority_out) {
+    if (!h) return fail(CRIM_ERR_ARG, "crim_peek_fields: null handle");
+    const Params& p = h->prm;
+    if (index < 0 || index >= p.B) return fail(CRIM_ERR_ARG, "crim_peek_fields: index %d of %d", index, p.B);
+    if (!h->uploaded[index]) return fail(CRIM_ERR_STATE, "crim_peek_fields: image %d was never uploaded", index);
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t HW = (size_t)p.H * p.W;
+    if (!h->d_peek) HIP_TRY(hipMalloc(&h->d_peek, HW * 17));
+    double* d_data = (double*)h->d_peek;
+    double* d_prio = d_data + HW;
+    uint8_t* d_front = (uint8_t*)(d_prio + HW);
+    hipLaunchKernelGGL(k_fields, dim3(p.tnx, p.tny), dim3(256), 0, h->stream, p, index, d_front, d_data, d_prio);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (front_out) HIP_TRY(hipMemcpy(front_out, d_front, HW, hipMemcpyDeviceToHost));
+    if (data_out) HIP_TRY(hipMemcpy(data_out, d_data, HW * sizeof(double), hipMemcpyDeviceToHost));
+    if (priority_out) HIP_TRY(hipMemcpy(priority_out, d_prio, HW * sizeof(double), hipMemcpyDeviceToHost));
+    return CRIM_OK;
+}

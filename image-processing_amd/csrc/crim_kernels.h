@@ -1,0 +1,925 @@
+// HIP kernels of the Criminisi engine for gfx950 (wave64).  Every floating-point expression
+// below is evaluated as written, in double precision, with FMA contraction disabled at build
+// time (-ffp-contract=off): the confidence, data and priority terms and the search cost must
+// reproduce NumPy's results bit for bit, because arg-max / arg-min ties decide which patch is
+// filled next.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "crim_types.h"
+
+// ------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------
+
+// BORDER_REFLECT_101 for offsets of one pixel (cv2.Laplacian / cv2.filter2D defaults,
+// criminisi_inpainter.py:103,149-150).
+__device__ __forceinline__ int reflect101(int i, int n) {
+    if (n == 1) return 0;
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * (n - 1) - i;
+    return i;
+}
+
+// Read-only, wave-uniform data written by an EARLIER kernel (the target descriptor) is read
+// through the constant address space so that the compiler emits scalar loads and the values
+// become SGPR operands of the dot products.
+typedef const uint32_t __attribute__((address_space(4))) * const_u32_ptr;
+__device__ __forceinline__ const_u32_ptr as_const_u32(const void* p) {
+    return (const_u32_ptr)(uintptr_t)p;
+}
+
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+
+// Reads element e of a row-major ph x pw window of the confidence map (flattened order).
+struct PatchReader {
+    const double* c;
+    int W, r0, c0, pw;
+    unsigned inv;  // ceil(65536 / pw): exact floor(e / pw) for e < 2048, pw <= 31
+    __device__ __forceinline__ double operator()(int e) const {
+        unsigned q = ((unsigned)e * inv) >> 16;
+        int col = e - (int)q * pw;
+        return c[(size_t)(r0 + (int)q) * W + c0 + col];
+    }
+};
+
+// NumPy's pairwise summation of n <= 128 doubles (np.sum in criminisi_inpainter.py:124-125
+// flattens the patch in C order): fewer than 8 elements are added sequentially, otherwise eight
+// interleaved accumulators are combined as ((0+1)+(2+3))+((4+5)+(6+7)) and the tail is added.
+__device__ __forceinline__ double pw_leaf(const PatchReader& a, int lo, int n) {
+    if (n < 8) {
+        double r = -0.0;
+        for (int i = 0; i < n; ++i) r += a(lo + i);
+        return r;
+    }
+    double r0 = a(lo), r1 = a(lo + 1), r2 = a(lo + 2), r3 = a(lo + 3);
+    double r4 = a(lo + 4), r5 = a(lo + 5), r6 = a(lo + 6), r7 = a(lo + 7);
+    int i;
+    const int lim = n - (n % 8);
+    for (i = 8; i < lim; i += 8) {
+        r0 += a(lo + i);
+        r1 += a(lo + i + 1);
+        r2 += a(lo + i + 2);
+        r3 += a(lo + i + 3);
+        r4 += a(lo + i + 4);
+        r5 += a(lo + i + 5);
+        r6 += a(lo + i + 6);
+        r7 += a(lo + i + 7);
+    }
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; ++i) res += a(lo + i);
+    return res;
+}
+
+// Larger windows are halved (first half rounded down to a multiple of 8) and the halves summed,
+// as NumPy does.  Depth 3 covers n <= 1024, i.e. patch edges up to 31.
+template <int D>
+__device__ __forceinline__ double pw_sum(const PatchReader& a, int lo, int n) {
+    if (n <= 128) return pw_leaf(a, lo, n);
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return pw_sum<D - 1>(a, lo, n2) + pw_sum<D - 1>(a, lo + n2, n - n2);
+}
+template <>
+__device__ __forceinline__ double pw_sum<0>(const PatchReader& a, int lo, int n) {
+    return pw_leaf(a, lo, n);
+}
+
+// Fill-front weight of pixel (y, x): sat_u8(Laplacian_ksize3(mask)) with the aperture
+// [[2,0,2],[0,-8,0],[2,0,2]] (criminisi_inpainter.py:103).  Also returns the 3x3 mask
+// neighbourhood in nb[] (row-major) for the normal.
+__device__ __forceinline__ int front_weight(const uint8_t* mask, int H, int W, int y, int x,
+                                            int nb[9]) {
+    const int ym = reflect101(y - 1, H), yp = reflect101(y + 1, H);
+    const int xm = reflect101(x - 1, W), xp = reflect101(x + 1, W);
+    const uint8_t* r0 = mask + (size_t)ym * W;
+    const uint8_t* r1 = mask + (size_t)y * W;
+    const uint8_t* r2 = mask + (size_t)yp * W;
+    nb[0] = r0[xm]; nb[1] = r0[x]; nb[2] = r0[xp];
+    nb[3] = r1[xm]; nb[4] = r1[x]; nb[5] = r1[xp];
+    nb[6] = r2[xm]; nb[7] = r2[x]; nb[8] = r2[xp];
+    int v = 2 * (nb[0] + nb[2] + nb[6] + nb[8]) - 8 * nb[4];
+    return v < 0 ? 0 : v;
+}
+
+struct FrontEval {
+    double cnew, data, prio;
+};
+
+// Confidence (criminisi_inpainter.py:114-127), data term (:129-214) and priority (:112) of one
+// front pixel.  ccur is the confidence map before this iteration's update.
+__device__ __forceinline__ FrontEval eval_front_pixel(const Params& p, const int* grad,
+                                                      const double* ccur, int y, int x, int F,
+                                                      const int nb[9]) {
+    const int H = p.H, W = p.W, half = p.half;
+    const int r0 = imax(0, y - half), r1 = imin(y + half, H - 1);
+    const int c0 = imax(0, x - half), c1 = imin(x + half, W - 1);
+    const int ph = r1 - r0 + 1, pw = c1 - c0 + 1;
+    PatchReader rd;
+    rd.c = ccur; rd.W = W; rd.r0 = r0; rd.c0 = c0; rd.pw = pw;
+    rd.inv = (65536u + (unsigned)pw - 1u) / (unsigned)pw;
+    FrontEval out;
+    out.cnew = pw_sum<3>(rd, 0, ph * pw) / (double)p.psq;
+
+    // mask normal (:138-164): Sobel/4 correlation, then normalised
+    const double a = nb[0], b = nb[1], c = nb[2], d = nb[3], f = nb[5], g = nb[6], h = nb[7],
+                 k = nb[8];
+    const double nx = .25 * a - .25 * c + .5 * d - .5 * f + .25 * g - .25 * k;
+    const double ny = -.25 * a - .5 * b - .25 * c + .25 * g + .5 * h + .25 * k;
+    double nrm = sqrt(ny * ny + nx * nx);
+    if (nrm == 0) nrm = 1;
+    const double ux = nx / nrm, uy = ny / nrm;
+
+    // first maximum of the gradient magnitude inside the patch (:183-211).  grad holds
+    // (2*gy, 2*gx) as integers; comparing 4*|g|^2 orders exactly like comparing sqrt(|g|^2).
+    int best = -1, by = 0, bx = 0;
+    for (int rr = r0; rr <= r1; ++rr) {
+        const int* grow = grad + (size_t)rr * W;
+        for (int cc = c0; cc <= c1; ++cc) {
+            const int gpk = grow[cc];
+            const int gy2 = (int)(short)(gpk & 0xffff), gx2 = gpk >> 16;
+            const int m = gy2 * gy2 + gx2 * gx2;
+            if (m > best) { best = m; by = gy2; bx = gx2; }
+        }
+    }
+    const double Gy = (double)by * 0.5, Gx = (double)bx * 0.5;
+    const double t0 = ux * Gy, t1 = uy * Gx;
+    out.data = sqrt(t0 * t0 + t1 * t1) + 0.001;
+    out.prio = out.cnew * out.data * (double)F;
+    return out;
+}
+
+// 2*d/dy and 2*d/dx of np.gradient (criminisi_inpainter.py:174) on the grey image with masked
+// pixels read as 0 (:171), packed as two int16.
+__device__ __forceinline__ int grad_packed(const uint8_t* grey, const uint8_t* mask, int H, int W,
+                                           int y, int x) {
+    auto G = [&](int yy, int xx) -> int {
+        const size_t i = (size_t)yy * W + xx;
+        return mask[i] ? 0 : (int)grey[i];
+    };
+    int gy2, gx2;
+    if (H == 1) gy2 = 0;
+    else if (y == 0) gy2 = 2 * (G(1, x) - G(0, x));
+    else if (y == H - 1) gy2 = 2 * (G(y, x) - G(y - 1, x));
+    else gy2 = G(y + 1, x) - G(y - 1, x);
+    if (W == 1) gx2 = 0;
+    else if (x == 0) gx2 = 2 * (G(y, 1) - G(y, 0));
+    else if (x == W - 1) gx2 = 2 * (G(y, x) - G(y, x - 1));
+    else gx2 = G(y, x + 1) - G(y, x - 1);
+    return (gy2 & 0xffff) | (int)((unsigned)gx2 << 16);
+}
+
+// Integer BGR -> Lab (cv2.COLOR_BGR2LAB on uint8, criminisi_inpainter.py:225) and the five
+// search planes derived from it: Lab - 128 per channel and Q = sum (Lab-128)^2 split as
+// Q % 255 and Q / 255, so that sum k*Q = dot(Q%255, k) + dot(Q/255, 255*k) stays in byte dot
+// products.
+__device__ __forceinline__ void lab_planes(const Params& p, int B_, int G_, int R_, uint8_t out[5]) {
+    const int b = p.gamma_tab[B_], g = p.gamma_tab[G_], r = p.gamma_tab[R_];
+    const int fX = p.cbrt_tab[(b * p.coef[0] + g * p.coef[1] + r * p.coef[2] + 2048) >> 12];
+    const int fY = p.cbrt_tab[(b * p.coef[3] + g * p.coef[4] + r * p.coef[5] + 2048) >> 12];
+    const int fZ = p.cbrt_tab[(b * p.coef[6] + g * p.coef[7] + r * p.coef[8] + 2048) >> 12];
+    int L = (296 * fY - 1336934 + 16384) >> 15;
+    int a = (500 * (fX - fY) + 128 * 32768 + 16384) >> 15;
+    int bb = (200 * (fY - fZ) + 128 * 32768 + 16384) >> 15;
+    L = imin(imax(L, 0), 255) - 128;
+    a = imin(imax(a, 0), 255) - 128;
+    bb = imin(imax(bb, 0), 255) - 128;
+    const int Q = L * L + a * a + bb * bb;
+    out[0] = (uint8_t)(int8_t)L;
+    out[1] = (uint8_t)(int8_t)a;
+    out[2] = (uint8_t)(int8_t)bb;
+    out[3] = (uint8_t)(Q % 255);
+    out[4] = (uint8_t)(Q / 255);
+}
+
+// ------------------------------------------------------------------------------------------
+// upload-time kernels
+// ------------------------------------------------------------------------------------------
+
+// One block per 16x16 tile: normalises the mask to {0,1}, derives confidence, grey and the
+// search planes, counts masked pixels per tile and grows the image's mask bounding box.
+__global__ __launch_bounds__(256) void k_init_pixels(Params p, int first, int* bbox) {
+    const int b = first + blockIdx.z;
+    const int y = blockIdx.y * CRIM_TILE + (threadIdx.x >> 4);
+    const int x = blockIdx.x * CRIM_TILE + (threadIdx.x & 15);
+    const size_t HW = (size_t)p.H * p.W;
+    int m = 0;
+    if (y < p.H && x < p.W) {
+        const size_t i = (size_t)y * p.W + x;
+        uint8_t* mk = p.mask + b * HW;
+        m = mk[i] ? 1 : 0;
+        mk[i] = (uint8_t)m;
+        const double c = 1.0 - (double)m;
+        p.conf[(b * 2 + 0) * HW + i] = c;
+        p.conf[(b * 2 + 1) * HW + i] = c;
+        const uint8_t* px = p.bgr + (b * HW + i) * 3;
+        const int B_ = px[0], G_ = px[1], R_ = px[2];
+        p.grey[b * HW + i] = (uint8_t)((B_ * 3735 + G_ * 19235 + R_ * 9798 + 16384) >> 15);
+        uint8_t pl[5];
+        lab_planes(p, B_, G_, R_, pl);
+        uint8_t* base = p.planes + (size_t)b * 5 * p.H * p.Wp + (size_t)y * p.Wp + x;
+        for (int k = 0; k < 5; ++k) base[(size_t)k * p.H * p.Wp] = pl[k];
+        if (m) {
+            int* bb = bbox + 4 * b;
+            atomicMin(&bb[0], y); atomicMax(&bb[1], y);
+            atomicMin(&bb[2], x); atomicMax(&bb[3], x);
+        }
+    }
+    const int cnt = __syncthreads_count(m);
+    if (threadIdx.x == 0) {
+        p.tilecnt[((size_t)b * p.tny + blockIdx.y) * p.tnx + blockIdx.x] = cnt;
+        if (cnt) atomicAdd(&p.st[b].remaining, cnt);
+    }
+}
+
+// Gradient field and window-validity map; needs the normalised mask of the whole image.
+__global__ __launch_bounds__(256) void k_init_fields(Params p, int first) {
+    const int b = first + blockIdx.z;
+    const int y = blockIdx.y * CRIM_TILE + (threadIdx.x >> 4);
+    const int x = blockIdx.x * CRIM_TILE + (threadIdx.x & 15);
+    if (y >= p.H || x >= p.W) return;
+    const size_t HW = (size_t)p.H * p.W;
+    const uint8_t* mk = p.mask + b * HW;
+    p.grad[b * HW + (size_t)y * p.W + x] = grad_packed(p.grey + b * HW, mk, p.H, p.W, y, x);
+    int inv = 1;
+    if (y <= p.H - p.P && x <= p.W - p.P) {
+        inv = 0;
+        for (int i = 0; i < p.P && !inv; ++i)
+            for (int j = 0; j < p.P; ++j)
+                if (mk[(size_t)(y + i) * p.W + x + j]) { inv = 1; break; }
+    }
+    p.invalid[((size_t)b * p.H + y) * p.Wi + x] = (uint8_t)inv;
+}
+
+__global__ void k_init_state(Params p, int first, int count, int* bbox) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    ImgState* s = p.st + first + i;
+    s->iter = 0; s->live = 1; s->cur = 0; s->remaining = 0; s->has_fix = 0;
+    s->fix_r0 = s->fix_r1 = s->fix_c0 = s->fix_c1 = 0;
+    s->pcount = 0; s->scount = 0; s->stalled = 0; s->bound = 0x7fffffff;
+    p.desc[first + i].live = 0;
+    int* bb = bbox + 4 * (first + i);
+    bb[0] = 0x7fffffff; bb[1] = -1; bb[2] = 0x7fffffff; bb[3] = -1;
+}
+
+// ------------------------------------------------------------------------------------------
+// iteration kernel 1: front, confidence, data, priority; per-tile arg-max
+// ------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ bool better_prio(double pa, int ia, double pb, int ib) {
+    return pa > pb || (pa == pb && ia < ib);
+}
+
+__global__ __launch_bounds__(256) void k_priority(Params p) {
+    const int b = blockIdx.z;
+    ImgState* st = p.st + b;
+    if (!st->live) return;
+    const int tX = p.ptx0 + blockIdx.x, tY = p.pty0 + blockIdx.y;
+    const int H = p.H, W = p.W;
+    const size_t HW = (size_t)H * W;
+
+    // A tile can hold front pixels only if it or a neighbouring tile holds masked pixels.
+    const int* tcnt = p.tilecnt + (size_t)b * p.tny * p.tnx;
+    int nbsum = 0;
+    for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int yy = tY + dy, xx = tX + dx;
+            if (yy >= 0 && yy < p.tny && xx >= 0 && xx < p.tnx) nbsum += tcnt[yy * p.tnx + xx];
+        }
+    // Pixels written to the current confidence buffer by the previous iteration (its front and
+    // its filled patch) that are not rewritten now must be carried over to the other buffer;
+    // all of them lie within one pixel of the previous patch box.
+    const int has_fix = st->has_fix;
+    const int fr0 = st->fix_r0 - 1, fr1 = st->fix_r1 + 1, fc0 = st->fix_c0 - 1, fc1 = st->fix_c1 + 1;
+    const bool fix_tile = has_fix && tY * CRIM_TILE <= fr1 && tY * CRIM_TILE + CRIM_TILE - 1 >= fr0 &&
+                          tX * CRIM_TILE <= fc1 && tX * CRIM_TILE + CRIM_TILE - 1 >= fc0;
+    if (nbsum == 0 && !fix_tile) return;
+
+    const int cur = st->cur;
+    const double* ccur = p.conf + ((size_t)b * 2 + cur) * HW;
+    double* cnxt = p.conf + ((size_t)b * 2 + (cur ^ 1)) * HW;
+    const uint8_t* mask = p.mask + b * HW;
+    const int* grad = p.grad + b * HW;
+
+    __shared__ int s_n;
+    __shared__ int s_list[256];
+    __shared__ double s_bp[4];
+    __shared__ int s_bi[4];
+    const int tid = threadIdx.x;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+
+    const int y = tY * CRIM_TILE + (tid >> 4), x = tX * CRIM_TILE + (tid & 15);
+    int nb[9];
+    int F = 0;
+    if (y < H && x < W) {
+        F = front_weight(mask, H, W, y, x, nb);
+        if (F == 0 && fix_tile && y >= fr0 && y <= fr1 && x >= fc0 && x <= fc1)
+            cnxt[(size_t)y * W + x] = ccur[(size_t)y * W + x];
+    }
+    if (F > 0) s_list[atomicAdd(&s_n, 1)] = tid;
+    __syncthreads();
+    const int n = s_n;
+
+    double bestP = -1.0;
+    int bestI = 0x7fffffff;
+    if (tid < n) {
+        const int t = s_list[tid];
+        const int fy = tY * CRIM_TILE + (t >> 4), fx = tX * CRIM_TILE + (t & 15);
+        int fnb[9];
+        const int fF = front_weight(mask, H, W, fy, fx, fnb);
+        const FrontEval ev = eval_front_pixel(p, grad, ccur, fy, fx, fF, fnb);
+        cnxt[(size_t)fy * W + fx] = ev.cnew;
+        bestP = ev.prio;
+        bestI = fy * W + fx;
+    }
+    if (n == 0) return;
+    // block arg-max: highest priority, lowest row-major index on ties (np.argmax, :217)
+    for (int off = 32; off > 0; off >>= 1) {
+        const double op = __shfl_down(bestP, off);
+        const int oi = __shfl_down(bestI, off);
+        if (better_prio(op, oi, bestP, bestI)) { bestP = op; bestI = oi; }
+    }
+    if ((tid & 63) == 0) { s_bp[tid >> 6] = bestP; s_bi[tid >> 6] = bestI; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (better_prio(s_bp[w], s_bi[w], bestP, bestI)) { bestP = s_bp[w]; bestI = s_bi[w]; }
+        if (bestP >= 0.0) {
+            const unsigned k = atomicAdd(&st->pcount, 1u);
+            PEntry e;
+            e.prio = bestP; e.pos = bestI; e.pad = 0;
+            p.plist[(size_t)b * p.ptnx * p.ptny + k] = e;
+        }
+    }
+}
+
+// Full-frame front / data / priority of the iteration that would run next (debug / parity
+// instrument): same arithmetic as k_priority, no state is changed.
+__global__ __launch_bounds__(256) void k_fields(Params p, int b, uint8_t* front, double* data,
+                                                double* prio) {
+    const int y = blockIdx.y * CRIM_TILE + (threadIdx.x >> 4);
+    const int x = blockIdx.x * CRIM_TILE + (threadIdx.x & 15);
+    if (y >= p.H || x >= p.W) return;
+    const size_t HW = (size_t)p.H * p.W;
+    const ImgState* st = p.st + b;
+    const double* ccur = p.conf + ((size_t)b * 2 + st->cur) * HW;
+    int nb[9];
+    const int F = front_weight(p.mask + b * HW, p.H, p.W, y, x, nb);
+    const size_t i = (size_t)y * p.W + x;
+    if (front) front[i] = (uint8_t)F;
+    double dv = 0.001, pv = 0.0;   // off the front the gradient is zero: sqrt(0) + 0.001
+    if (F > 0) {
+        const FrontEval ev = eval_front_pixel(p, p.grad + b * HW, ccur, y, x, F, nb);
+        dv = ev.data;
+        pv = ev.prio;
+    }
+    if (data) data[i] = dv;
+    if (prio) prio[i] = pv;
+}
+
+// ------------------------------------------------------------------------------------------
+// iteration kernel 2: pick the target pixel, build the template descriptor
+// ------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_select(Params p) {
+    const int b = blockIdx.x;
+    ImgState* st = p.st + b;
+    Desc* d = p.desc + b;
+    const int tid = threadIdx.x;
+    if (!st->live) {
+        if (tid == 0) d->live = 0;
+        return;
+    }
+    const int H = p.H, W = p.W, P = p.P, ND = p.ND;
+    const size_t HW = (size_t)H * W;
+    __shared__ double s_bp[4];
+    __shared__ int s_bi[4];
+    __shared__ int s_target;
+    __shared__ uint8_t s_k[CRIM_PMAX * CRIM_PMAX];
+    __shared__ int8_t s_t[3][CRIM_PMAX * CRIM_PMAX];
+    __shared__ int s_soff;
+
+    const unsigned n = st->pcount;
+    const PEntry* pl = p.plist + (size_t)b * p.ptnx * p.ptny;
+    double bestP = -1.0;
+    int bestI = 0x7fffffff;
+    for (unsigned i = tid; i < n; i += 256) {
+        const PEntry e = pl[i];
+        if (better_prio(e.prio, e.pos, bestP, bestI)) { bestP = e.prio; bestI = e.pos; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double op = __shfl_down(bestP, off);
+        const int oi = __shfl_down(bestI, off);
+        if (better_prio(op, oi, bestP, bestI)) { bestP = op; bestI = oi; }
+    }
+    if ((tid & 63) == 0) { s_bp[tid >> 6] = bestP; s_bi[tid >> 6] = bestI; }
+    if (tid == 0) s_soff = 0;
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (better_prio(s_bp[w], s_bi[w], bestP, bestI)) { bestP = s_bp[w]; bestI = s_bi[w]; }
+        // empty front: the priority map is all zeros and np.argmax returns index 0
+        s_target = (bestP > 0.0) ? bestI : 0;
+    }
+    __syncthreads();
+    const int pos = s_target;
+    const int tr = pos / W, tc = pos - tr * W;
+    const int r0 = imax(0, tr - p.half), r1 = imin(tr + p.half, H - 1);
+    const int c0 = imax(0, tc - p.half), c1 = imin(tc + p.half, W - 1);
+    const int ph = r1 - r0 + 1, pw = c1 - c0 + 1;
+    const uint8_t* mask = p.mask + b * HW;
+    const uint8_t* planes = p.planes + (size_t)b * 5 * H * p.Wp;
+
+    int soff_local = 0;
+    for (int e = tid; e < P * P; e += 256) {
+        const int i = e / P, j = e - i * P;
+        int k = 0, t0 = 0, t1 = 0, t2 = 0;
+        if (i < ph && j < pw) {
+            const int yy = r0 + i, xx = c0 + j;
+            k = 1 - (int)mask[(size_t)yy * W + xx];
+            if (k) {
+                const size_t o = (size_t)yy * p.Wp + xx;
+                t0 = (int8_t)planes[o];
+                t1 = (int8_t)planes[(size_t)H * p.Wp + o];
+                t2 = (int8_t)planes[(size_t)2 * H * p.Wp + o];
+                // sum k*T~^2 - sum k*T^2 with T = T~ + 128
+                soff_local += -256 * (t0 + t1 + t2) - 3 * 16384;
+            }
+        }
+        s_k[e] = (uint8_t)k;
+        s_t[0][e] = (int8_t)t0; s_t[1][e] = (int8_t)t1; s_t[2][e] = (int8_t)t2;
+        d->kflat[e] = (uint8_t)k;
+        d->tflat[0][e] = (int8_t)t0; d->tflat[1][e] = (int8_t)t1; d->tflat[2][e] = (int8_t)t2;
+    }
+    if (soff_local) atomicAdd(&s_soff, soff_local);
+    __syncthreads();
+
+    // shifted template rows: dword j of shift s covers template columns 4j-s .. 4j-s+3
+    const int total = 5 * P * 4 * ND;
+    for (int e = tid; e < total; e += 256) {
+        const int j = e % ND;
+        const int s = (e / ND) & 3;
+        const int i = (e / (ND * 4)) % P;
+        const int type = e / (ND * 4 * P);
+        uint32_t v = 0;
+        for (int bb = 0; bb < 4; ++bb) {
+            const int col = 4 * j + bb - s;
+            uint32_t byte = 0;
+            if (col >= 0 && col < P) {
+                const int q = i * P + col;
+                if (type < 3) byte = (uint8_t)s_t[type][q];
+                else if (type == 3) byte = s_k[q];
+                else byte = s_k[q] ? 255u : 0u;
+            }
+            v |= byte << (8 * bb);
+        }
+        d->tmpl[e] = v;
+    }
+    if (tid == 0) {
+        int rowmask = 0;
+        for (int i = 0; i < P; ++i) {
+            int any = 0;
+            for (int j = 0; j < P; ++j) any |= s_k[i * P + j];
+            if (any) rowmask |= 1 << i;
+        }
+        d->live = 1;
+        d->tr = tr; d->tc = tc; d->r0 = r0; d->c0 = c0; d->ph = ph; d->pw = pw;
+        d->clipped = (ph != P || pw != P) ? 1 : 0;
+        d->ncy = H - ph + 1; d->ncx = W - pw + 1;
+        d->soff = s_soff;
+        d->rowmask = rowmask;
+        d->cnew = p.conf[((size_t)b * 2 + (st->cur ^ 1)) * HW + pos];
+        d->ty = (double)(r0 + r1) / 2.0;
+        d->tx = (double)(c0 + c1) / 2.0;
+        st->pcount = 0;
+        st->scount = 0;
+        st->bound = 0x7fffffff;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// iteration kernel 3: masked patch-SSD search
+// ------------------------------------------------------------------------------------------
+
+// Does the ph x pw window at origin (y, x) avoid every masked pixel (:250-255)?  The cached
+// map answers for full P x P windows; smaller (border-clipped) windows are contained in the
+// full window when that fits, and are scanned otherwise.
+__device__ __forceinline__ bool window_valid(const Params& p, const Desc* d, const uint8_t* inv,
+                                             const uint8_t* mask, int y, int x) {
+    if (y <= p.H - p.P && x <= p.W - p.P && inv[(size_t)y * p.Wi + x] == 0) return true;
+    if (!d->clipped) return false;
+    for (int i = 0; i < d->ph; ++i)
+        for (int j = 0; j < d->pw; ++j)
+            if (mask[(size_t)(y + i) * p.W + x + j]) return false;
+    return true;
+}
+
+__device__ __forceinline__ bool better_cost(double ca, unsigned ia, double cb, unsigned ib) {
+    return ca < cb || (ca == cb && ia < ib);
+}
+
+// cost = float64(S) + sqrt((y + ph/2 - ty)^2 + (x + pw/2 - tx)^2)   (:258-262)
+__device__ __forceinline__ double cand_cost(const Desc* d, int S, int y, int x) {
+    const double dy = ((double)y + (double)d->ph / 2.0) - d->ty;
+    const double dx = ((double)x + (double)d->pw / 2.0) - d->tx;
+    return (double)S + sqrt(dy * dy + dx * dx);
+}
+
+__device__ __forceinline__ void block_min_emit(const Params& p, int b, double bc, unsigned bi,
+                                               double* s_c, unsigned* s_i) {
+    const int tid = threadIdx.x;
+    for (int off = 32; off > 0; off >>= 1) {
+        const double oc = __shfl_down(bc, off);
+        const unsigned oi = __shfl_down(bi, off);
+        if (better_cost(oc, oi, bc, bi)) { bc = oc; bi = oi; }
+    }
+    if ((tid & 63) == 0) { s_c[tid >> 6] = bc; s_i[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (better_cost(s_c[w], s_i[w], bc, bi)) { bc = s_c[w]; bi = s_i[w]; }
+        if (bi != 0xffffffffu) {
+            const unsigned k = atomicAdd(&p.st[b].scount, 1u);
+            SEntry e;
+            e.cost = bc; e.idx = bi; e.pad = 0;
+            p.slist[(size_t)b * p.snx * p.sny + k] = e;
+        }
+    }
+}
+
+// Specialised search: each thread scores 4 consecutive x origins (one dword of every byte
+// plane serves all four through pre-shifted templates) for SB_R consecutive rows; plane tiles
+// are staged through LDS once per block; template dwords are wave-uniform scalar operands of
+// v_dot4.  S_centred = dot(Q%255, k) + dot(Q/255, 255k) - 2 * sum_ch dot(Lab_ch-128, k*T_ch).
+template <int P>
+__global__ __launch_bounds__(256) void k_search(Params p) {
+    constexpr int ND = (P + 6) / 4;
+    constexpr int R = SB_R;
+    constexpr int LROWS = SB_H + P - 1;
+    constexpr int LCOLS = SB_TXG + ND - 1;
+    __shared__ uint32_t lds[5][LROWS][LCOLS];
+    __shared__ double s_c[4];
+    __shared__ unsigned s_i[4];
+    __shared__ int s_bound;
+
+    const int b = blockIdx.z;
+    const Desc* __restrict__ d = p.desc + b;
+    if (!d->live) return;
+    const int ncy = d->ncy, ncx = d->ncx;
+    const int y0 = blockIdx.y * SB_H, x0 = blockIdx.x * SB_W;
+    if (y0 >= ncy || x0 >= ncx) return;
+    const int tid = threadIdx.x, tx = tid & (SB_TXG - 1), ty = tid / SB_TXG;
+    if (tid == 0) s_bound = __hip_atomic_load(&p.st[b].bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int H = p.H, W = p.W;
+    const size_t HW = (size_t)H * W;
+    const uint8_t* inv = p.invalid + (size_t)b * H * p.Wi;
+    const uint8_t* mask = p.mask + b * HW;
+
+    // which of this thread's 4 x R origins are admissible
+    unsigned vbits = 0;
+    const int xg = x0 + 4 * tx;
+    if (!d->clipped) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int y = y0 + ty * R + r;
+            if (y < ncy && xg < ncx) {
+                const uint32_t iv = *(const uint32_t*)(inv + (size_t)y * p.Wi + xg);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    if (xg + s < ncx && ((iv >> (8 * s)) & 0xffu) == 0) vbits |= 1u << (r * 4 + s);
+            }
+        }
+    } else {
+        for (int r = 0; r < R; ++r) {
+            const int y = y0 + ty * R + r;
+            for (int s = 0; s < 4; ++s)
+                if (y < ncy && xg + s < ncx && window_valid(p, d, inv, mask, y, xg + s))
+                    vbits |= 1u << (r * 4 + s);
+        }
+    }
+    if (!__syncthreads_or(vbits != 0)) return;
+
+    // stage the five byte planes of this tile (zero beyond the image)
+    const uint8_t* pl = p.planes + (size_t)b * 5 * H * p.Wp;
+    uint32_t* lflat = &lds[0][0][0];
+    for (int idx = tid; idx < 5 * LROWS * LCOLS; idx += 256) {
+        const int pln = idx / (LROWS * LCOLS);
+        const int rem = idx - pln * (LROWS * LCOLS);
+        const int row = rem / LCOLS, col = rem - row * LCOLS;
+        const int gy = y0 + row, gx = x0 + 4 * col;
+        uint32_t v = 0;
+        if (gy < H && gx < p.Wp) v = *(const uint32_t*)(pl + ((size_t)pln * H + gy) * p.Wp + gx);
+        lflat[idx] = v;
+    }
+    __syncthreads();
+
+    double bc = INFINITY;
+    unsigned bi = 0xffffffffu;
+    int Sv[R][4];
+    int smin = 0x7fffffff, kr = -1, ks = 0;
+    if (vbits) {
+        int accC[R][4], accQ[R][4];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { accC[r][s] = 0; accQ[r][s] = 0; }
+        const_u32_ptr tm = as_const_u32(d->tmpl);
+#pragma unroll 1
+        for (int ch = 0; ch < 3; ++ch) {
+            uint32_t img[R + P - 1][ND];
+#pragma unroll
+            for (int rr = 0; rr < R + P - 1; ++rr)
+#pragma unroll
+                for (int j = 0; j < ND; ++j) img[rr][j] = lds[ch][ty * R + rr][tx + j];
+            const_u32_ptr t = tm + ch * (P * 4 * ND);
+#pragma unroll
+            for (int i = 0; i < P; ++i)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int j = 0; j < ND; ++j) {
+                        const int tv = (int)t[(i * 4 + s) * ND + j];
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+                            accC[r][s] = __builtin_amdgcn_sdot4((int)img[r + i][j], tv, accC[r][s], false);
+                    }
+        }
+#pragma unroll 1
+        for (int q = 0; q < 2; ++q) {
+            uint32_t img[R + P - 1][ND];
+#pragma unroll
+            for (int rr = 0; rr < R + P - 1; ++rr)
+#pragma unroll
+                for (int j = 0; j < ND; ++j) img[rr][j] = lds[3 + q][ty * R + rr][tx + j];
+            const_u32_ptr t = tm + (3 + q) * (P * 4 * ND);
+#pragma unroll
+            for (int i = 0; i < P; ++i)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int j = 0; j < ND; ++j) {
+                        const uint32_t tv = t[(i * 4 + s) * ND + j];
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+                            accQ[r][s] = (int)__builtin_amdgcn_udot4(img[r + i][j], tv, (uint32_t)accQ[r][s], false);
+                    }
+        }
+        const int soff = d->soff;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                Sv[r][s] = accQ[r][s] - 2 * accC[r][s] + soff;
+                if ((vbits & (1u << (r * 4 + s))) && Sv[r][s] < smin) { smin = Sv[r][s]; kr = r; ks = s; }
+            }
+    }
+    // The distance term is never negative, so a window's cost is at least its integer S.
+    // Phase A: every thread prices only its lowest-S window exactly; the smallest integer
+    // strictly above any priced cost bounds the minimum from above (block-wide through LDS,
+    // grid-wide through a relaxed global word; a stale bound only prunes less).
+    // Phase B: the other windows are priced only if their S does not exceed that bound, so no
+    // window that could reach or tie the minimum is skipped.
+    const int gbound = s_bound;
+    if (kr >= 0 && smin <= gbound) {
+        const int y = y0 + ty * R + kr, x = xg + ks;
+        bc = cand_cost(d, smin, y, x);
+        bi = (unsigned)y * (unsigned)ncx + (unsigned)x;
+        const double ubd = floor(bc) + 1.0;
+        const int ub = ubd < 2147483647.0 ? (int)ubd : 0x7fffffff;
+        if (ub < gbound) atomicMin(&s_bound, ub);
+    }
+    __syncthreads();
+    const int ub = s_bound;
+    if (vbits) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                if ((vbits & (1u << (r * 4 + s))) && !(r == kr && s == ks) && Sv[r][s] <= ub) {
+                    const int y = y0 + ty * R + r, x = xg + s;
+                    const double c = cand_cost(d, Sv[r][s], y, x);
+                    const unsigned idx = (unsigned)y * (unsigned)ncx + (unsigned)x;
+                    if (better_cost(c, idx, bc, bi)) { bc = c; bi = idx; }
+                }
+    }
+    if (tid == 0 && ub < gbound) atomicMin(&p.st[b].bound, ub);
+    block_min_emit(p, b, bc, bi, s_c, s_i);
+}
+
+// Unspecialised search for any patch edge: one origin at a time, planes read from global
+// memory, templates from the flat byte arrays.
+__global__ __launch_bounds__(256) void k_search_generic(Params p) {
+    __shared__ double s_c[4];
+    __shared__ unsigned s_i[4];
+    const int b = blockIdx.z;
+    const Desc* __restrict__ d = p.desc + b;
+    if (!d->live) return;
+    const int ncy = d->ncy, ncx = d->ncx;
+    const int y0 = blockIdx.y * SB_H, x0 = blockIdx.x * SB_W;
+    if (y0 >= ncy || x0 >= ncx) return;
+    const int tid = threadIdx.x;
+    const int H = p.H, W = p.W, P = p.P;
+    const size_t HW = (size_t)H * W;
+    const uint8_t* inv = p.invalid + (size_t)b * H * p.Wi;
+    const uint8_t* mask = p.mask + b * HW;
+    const uint8_t* pl = p.planes + (size_t)b * 5 * H * p.Wp;
+    const size_t PS = (size_t)H * p.Wp;
+    const int ph = d->ph, pw = d->pw, soff = d->soff;
+    double bc = INFINITY;
+    unsigned bi = 0xffffffffu;
+    for (int e = tid; e < SB_W * SB_H; e += 256) {
+        const int y = y0 + e / SB_W, x = x0 + e % SB_W;
+        if (y >= ncy || x >= ncx) continue;
+        if (!window_valid(p, d, inv, mask, y, x)) continue;
+        int accQ = 0, accC = 0;
+        for (int i = 0; i < ph; ++i)
+            for (int j = 0; j < pw; ++j) {
+                const int q = i * P + j;
+                if (!d->kflat[q]) continue;
+                const size_t o = (size_t)(y + i) * p.Wp + x + j;
+                accQ += (int)pl[3 * PS + o] + 255 * (int)pl[4 * PS + o];
+                accC += (int)(int8_t)pl[o] * (int)d->tflat[0][q] +
+                        (int)(int8_t)pl[PS + o] * (int)d->tflat[1][q] +
+                        (int)(int8_t)pl[2 * PS + o] * (int)d->tflat[2][q];
+            }
+        const int S = accQ - 2 * accC + soff;
+        if ((double)S <= bc) {
+            const double c = cand_cost(d, S, y, x);
+            const unsigned idx = (unsigned)y * (unsigned)ncx + (unsigned)x;
+            if (better_cost(c, idx, bc, bi)) { bc = c; bi = idx; }
+        }
+    }
+    block_min_emit(p, b, bc, bi, s_c, s_i);
+}
+
+// ------------------------------------------------------------------------------------------
+// iteration kernel 4: pick the source, copy the patch, maintain every cached field
+// ------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_update(Params p) {
+    const int b = blockIdx.x;
+    ImgState* st = p.st + b;
+    if (!st->live) return;
+    const Desc* __restrict__ d = p.desc + b;
+    const int tid = threadIdx.x;
+    const int H = p.H, W = p.W, P = p.P;
+    const size_t HW = (size_t)H * W;
+    constexpr int PM = CRIM_PMAX;
+    constexpr int MR = 3 * PM - 2;    // mask region edge for the validity update
+    constexpr int GR = PM + 4;        // grey region edge for the gradient update
+    __shared__ double s_c[4];
+    __shared__ unsigned s_i[4];
+    __shared__ unsigned s_src;
+    __shared__ double s_cost;
+    __shared__ int s_filled;
+    __shared__ uint8_t s_px[PM * PM][9];   // source pixel: B,G,R, 5 planes, grey
+    __shared__ uint8_t s_m[MR * MR];
+    __shared__ uint8_t s_g[GR * GR];
+
+    // ---- arg-min over the per-block candidates: lowest cost, lowest row-major index (:264)
+    const unsigned n = st->scount;
+    const SEntry* sl = p.slist + (size_t)b * p.snx * p.sny;
+    double bc = INFINITY;
+    unsigned bi = 0xffffffffu;
+    for (unsigned i = tid; i < n; i += 256) {
+        const SEntry e = sl[i];
+        if (better_cost(e.cost, e.idx, bc, bi)) { bc = e.cost; bi = e.idx; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double oc = __shfl_down(bc, off);
+        const unsigned oi = __shfl_down(bi, off);
+        if (better_cost(oc, oi, bc, bi)) { bc = oc; bi = oi; }
+    }
+    if ((tid & 63) == 0) { s_c[tid >> 6] = bc; s_i[tid >> 6] = bi; }
+    if (tid == 0) s_filled = 0;
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (better_cost(s_c[w], s_i[w], bc, bi)) { bc = s_c[w]; bi = s_i[w]; }
+        // no admissible window: every cost is +inf and np.argmin returns index 0
+        s_src = (bi == 0xffffffffu) ? 0u : bi;
+        s_cost = bc;
+    }
+    __syncthreads();
+    const int ncx = d->ncx;
+    const int sy = (int)(s_src / (unsigned)ncx), sx = (int)(s_src % (unsigned)ncx);
+    const int r0 = d->r0, c0 = d->c0, ph = d->ph, pw = d->pw;
+    const int r1 = r0 + ph - 1, c1 = c0 + pw - 1;
+    uint8_t* mask = p.mask + b * HW;
+    uint8_t* bgr = p.bgr + b * HW * 3;
+    uint8_t* grey = p.grey + b * HW;
+    uint8_t* planes = p.planes + (size_t)b * 5 * H * p.Wp;
+    const size_t PS = (size_t)H * p.Wp;
+    double* cnxt = p.conf + ((size_t)b * 2 + (st->cur ^ 1)) * HW;
+
+    // ---- snapshot: source pixels, the mask around the patch, the grey values around it
+    for (int e = tid; e < ph * pw; e += 256) {
+        const int i = e / pw, j = e - i * pw;
+        const size_t s = (size_t)(sy + i) * W + sx + j;
+        const size_t so = (size_t)(sy + i) * p.Wp + sx + j;
+        s_px[e][0] = bgr[3 * s]; s_px[e][1] = bgr[3 * s + 1]; s_px[e][2] = bgr[3 * s + 2];
+        for (int k = 0; k < 5; ++k) s_px[e][3 + k] = planes[k * PS + so];
+        s_px[e][8] = grey[s];
+    }
+    const int mr0 = r0 - (P - 1), mc0 = c0 - (P - 1);
+    const int mrh = ph + 2 * (P - 1), mrw = pw + 2 * (P - 1);
+    for (int e = tid; e < mrh * mrw; e += 256) {
+        const int i = e / mrw, j = e - i * mrw;
+        const int yy = mr0 + i, xx = mc0 + j;
+        uint8_t v = 1;   // beyond the image: a window reaching there is not a candidate
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = mask[(size_t)yy * W + xx];
+        s_m[i * MR + j] = v;
+    }
+    const int gr0 = r0 - 2, gc0 = c0 - 2, grh = ph + 4, grw = pw + 4;
+    for (int e = tid; e < grh * grw; e += 256) {
+        const int i = e / grw, j = e - i * grw;
+        const int yy = gr0 + i, xx = gc0 + j;
+        uint8_t v = 0;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+            const size_t q = (size_t)yy * W + xx;
+            v = mask[q] ? (uint8_t)0 : grey[q];
+        }
+        s_g[i * GR + j] = v;
+    }
+    __syncthreads();
+
+    // ---- fill the masked pixels of the target patch (:274-308)
+    const double cnew = d->cnew;
+    int* tcnt = p.tilecnt + (size_t)b * p.tny * p.tnx;
+    int filled = 0;
+    for (int e = tid; e < ph * pw; e += 256) {
+        const int i = e / pw, j = e - i * pw;
+        const int yy = r0 + i, xx = c0 + j;
+        const size_t q = (size_t)yy * W + xx;
+        if (mask[q]) {
+            bgr[3 * q] = s_px[e][0]; bgr[3 * q + 1] = s_px[e][1]; bgr[3 * q + 2] = s_px[e][2];
+            const size_t qo = (size_t)yy * p.Wp + xx;
+            for (int k = 0; k < 5; ++k) planes[k * PS + qo] = s_px[e][3 + k];
+            grey[q] = s_px[e][8];
+            cnxt[q] = cnew;
+            mask[q] = 0;
+            s_m[(i + P - 1) * MR + (j + P - 1)] = 0;
+            s_g[(i + 2) * GR + (j + 2)] = s_px[e][8];
+            atomicSub(&tcnt[(yy / CRIM_TILE) * p.tnx + xx / CRIM_TILE], 1);
+            ++filled;
+        }
+    }
+    if (filled) atomicAdd(&s_filled, filled);
+    __syncthreads();
+
+    // ---- window-validity map: origins whose P x P window touches the patch
+    uint8_t* inv = p.invalid + (size_t)b * H * p.Wi;
+    const int oh = ph + P - 1, ow = pw + P - 1;   // origins r0-P+1 .. r1, c0-P+1 .. c1
+    for (int e = tid; e < oh * ow; e += 256) {
+        const int i = e / ow, j = e - i * ow;
+        const int oy = mr0 + i, ox = mc0 + j;
+        if (oy < 0 || ox < 0 || oy > H - P || ox > W - P) continue;
+        int any = 0;
+        for (int a = 0; a < P && !any; ++a)
+            for (int c = 0; c < P; ++c)
+                if (s_m[(i + a) * MR + j + c]) { any = 1; break; }
+        inv[(size_t)oy * p.Wi + ox] = (uint8_t)any;
+    }
+    // ---- gradient field: pixels within one pixel of the patch
+    int* grad = p.grad + b * HW;
+    const int uh = ph + 2, uw = pw + 2;
+    for (int e = tid; e < uh * uw; e += 256) {
+        const int i = e / uw, j = e - i * uw;
+        const int yy = r0 - 1 + i, xx = c0 - 1 + j;
+        if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+        auto G = [&](int y2, int x2) -> int { return (int)s_g[(y2 - gr0) * GR + (x2 - gc0)]; };
+        int gy2, gx2;
+        if (H == 1) gy2 = 0;
+        else if (yy == 0) gy2 = 2 * (G(1, xx) - G(0, xx));
+        else if (yy == H - 1) gy2 = 2 * (G(yy, xx) - G(yy - 1, xx));
+        else gy2 = G(yy + 1, xx) - G(yy - 1, xx);
+        if (W == 1) gx2 = 0;
+        else if (xx == 0) gx2 = 2 * (G(yy, 1) - G(yy, 0));
+        else if (xx == W - 1) gx2 = 2 * (G(yy, xx) - G(yy, xx - 1));
+        else gx2 = G(yy, xx + 1) - G(yy, xx - 1);
+        grad[(size_t)yy * W + xx] = (gy2 & 0xffff) | (int)((unsigned)gx2 << 16);
+    }
+    // ---- loop state and trace
+    if (tid == 0) {
+        const int nf = s_filled;
+        const int rem = st->remaining - nf;
+        const int it = st->iter;
+        if (p.trace && it < p.trace_cap) {
+            crim_iter_rec rec;
+            rec.tr = d->tr; rec.tc = d->tc; rec.sy = sy; rec.sx = sx;
+            rec.cost = s_cost; rec.remaining = rem;
+            p.trace[(size_t)b * p.trace_cap + it] = rec;
+        }
+        st->remaining = rem;
+        st->iter = it + 1;
+        st->cur ^= 1;
+        st->has_fix = 1;
+        st->fix_r0 = r0; st->fix_r1 = r1; st->fix_c0 = c0; st->fix_c1 = c1;
+        if (rem <= 0) st->live = 0;
+        else if (nf == 0) { st->live = 0; st->stalled = 1; }
+    }
+}

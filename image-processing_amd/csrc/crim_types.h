@@ -1,0 +1,96 @@
+// Device/host shared data layout of the Criminisi engine (gfx950).
+#pragma once
+#include <stdint.h>
+
+#include "../../include/criminisi_hip.h"
+
+#define CRIM_TILE 16          // edge of a priority-scan tile (pixels)
+#define CRIM_PMAX CRIM_MAX_PATCH
+#define CRIM_NDMAX ((CRIM_PMAX + 6) / 4)
+
+// Search-kernel tiling: a 256-thread block scores SB_TXG*4 x SB_TYT*SB_R candidate origins.
+#define SB_TXG 32   // groups of 4 consecutive x origins per block row
+#define SB_TYT 8    // thread rows per block
+#define SB_R 4      // origin rows per thread
+#define SB_W (SB_TXG * 4)
+#define SB_H (SB_TYT * SB_R)
+
+// Per-image loop state, advanced on the device so that a replayed hipGraph needs no host input.
+struct ImgState {
+    int iter;        // iterations executed so far
+    int live;        // 1 while the next iteration must run
+    int cur;         // which of the two confidence buffers is current
+    int remaining;   // masked pixels left
+    int has_fix;     // a previous iteration exists: its patch box needs the buffer fix-up
+    int fix_r0, fix_r1, fix_c0, fix_c1;
+    unsigned pcount; // entries in this image's priority partial list
+    unsigned scount; // entries in this image's search partial list
+    int stalled;     // an iteration filled nothing while pixels remained
+    int bound;       // running upper bound on floor(best cost) for search pruning
+    int pad[3];
+};
+
+// Best front pixel of one priority tile.
+struct PEntry {
+    double prio;
+    int pos;
+    int pad;
+};
+
+// Best candidate of one search block.
+struct SEntry {
+    double cost;
+    unsigned idx;
+    unsigned pad;
+};
+
+// Target-patch descriptor, rebuilt every iteration by the select kernel.
+struct Desc {
+    int live;
+    int tr, tc;          // target pixel
+    int r0, c0, ph, pw;  // target patch (clipped to the image)
+    int clipped;         // ph or pw smaller than the full patch edge
+    int ncy, ncx;        // candidate grid: H-ph+1, W-pw+1
+    int soff;            // S_reference = S_centred + soff
+    int rowmask;         // bit i set: template row i has at least one known pixel
+    double cnew;         // updated confidence at the target pixel
+    double ty, tx;       // patch centre as the reference computes it
+    // Templates as byte planes, zero padded: kflat = 1 - mask, tflat = k * (Lab - 128).
+    uint8_t kflat[CRIM_PMAX * CRIM_PMAX];
+    int8_t tflat[3][CRIM_PMAX * CRIM_PMAX];
+    // Pre-shifted dword rows for the dot4 kernels: [type][row][shift][dword], type 0..2 =
+    // k*T per Lab channel (signed), 3 = k, 4 = 255*k (unsigned).  Dimensions are the
+    // engine's P and ND (compact, not CRIM_PMAX).
+    uint32_t tmpl[5 * CRIM_PMAX * 4 * CRIM_NDMAX];
+};
+
+struct Params {
+    int B, H, W;
+    int P;        // patch edge 2*((patch_size-1)/2)+1
+    int half;
+    int psq;      // patch_size squared: the confidence divisor
+    int ND;       // dwords per shifted template row
+    int Wp;       // pitch of the search byte planes
+    int Wi;       // pitch of the window-validity map
+    int tnx, tny; // priority tile grid over the whole image
+    int ptx0, pty0, ptnx, ptny;  // tile window the priority scan covers
+    int snx, sny; // search block grid
+    int generic;  // use the unspecialised search kernel
+    long trace_cap;
+    uint8_t* bgr;      // [B][H][W][3]
+    uint8_t* planes;   // [B][5][H][Wp]  L-128, a-128, b-128 (int8), Q%255, Q/255 (uint8)
+    uint8_t* mask;     // [B][H][W]
+    uint8_t* grey;     // [B][H][W]
+    int* grad;         // [B][H][W] packed (int16 2*gy, int16 2*gx)
+    double* conf;      // [B][2][H][W]
+    uint8_t* invalid;  // [B][H][Wi] 1: the P x P window at this origin holds a masked pixel
+    int* tilecnt;      // [B][tny][tnx] masked pixels per tile
+    ImgState* st;
+    Desc* desc;
+    PEntry* plist;     // [B][ptnx*ptny]
+    SEntry* slist;     // [B][snx*sny]
+    crim_iter_rec* trace;  // [B][trace_cap]
+    const uint16_t* gamma_tab;
+    const uint16_t* cbrt_tab;
+    int coef[9];
+};

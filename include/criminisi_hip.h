@@ -1,0 +1,119 @@
+/*
+ * C ABI of libcriminisi_hip.so: a device-resident Criminisi exemplar-inpainting engine for
+ * AMD MI355X (gfx950).
+ *
+ * The reference (Theosdoor/Image-Processing) is pure Python and has no FFI; its only interface
+ * for this path is the class Criminisi_Inpainter(image, mask, patch_size, verbose,
+ * show_progress) with .inpaint() (src/criminisi_inpainter.py:7,18,40-88), constructed once per
+ * image by src/utils.py:102-103.  The entry points below are what a ctypes binding for that
+ * class needs: create an engine for one image shape, hand over image + mask, run the fill loop
+ * to completion on the GPU, read back the result and (for parity checks) the per-iteration
+ * decisions.  Each declaration cites the reference lines it replaces.
+ *
+ * Conventions: every function returns CRIM_OK (0) or a positive error code and never aborts;
+ * crim_last_error() gives the message for the calling thread's last failure.  A handle may be
+ * used from one host thread at a time; different handles may be used concurrently.  Images
+ * are uint8 H x W x 3 in B,G,R order; masks are uint8 H x W, nonzero = pixel to fill.
+ */
+#ifndef CRIMINISI_HIP_H
+#define CRIMINISI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct crim_engine crim_t;
+
+/* One record per executed iteration of the fill loop (src/criminisi_inpainter.py:51-83):
+ * the target pixel chosen at :62, the top-left corner of the source patch chosen at :65
+ * (:264-265), the fp64 cost of that patch (:247-262) and the number of masked pixels left
+ * after the update (:74). */
+typedef struct crim_iter_rec {
+    int32_t tr, tc;
+    int32_t sy, sx;
+    double cost;
+    int64_t remaining;
+} crim_iter_rec;
+
+enum {
+    CRIM_OK = 0,
+    CRIM_ERR_ARG = 1,         /* bad argument (null pointer, size out of range, index) */
+    CRIM_ERR_HIP = 2,         /* a HIP runtime call failed; see crim_last_error() */
+    CRIM_ERR_STATE = 3,       /* call made in the wrong order (run before upload, ...) */
+    CRIM_ERR_NO_PROGRESS = 4, /* an iteration filled nothing while pixels remain: the reference
+                                 loop (:51-83) would never terminate on this input */
+    CRIM_ERR_NOMEM = 5
+};
+
+/* crim_create* flags */
+enum {
+    CRIM_FLAG_EAGER = 1u,          /* launch kernels one by one instead of replaying a hipGraph */
+    CRIM_FLAG_PROFILE = 2u,        /* bracket every search launch with HIP events (implies eager) */
+    CRIM_FLAG_GENERIC_SEARCH = 4u  /* use the unspecialised search kernel for every patch size */
+};
+
+/* Largest patch_size accepted.  The reference takes any integer (:18); the bit-exact regime
+ * of its float32 SSD is patch_size <= 16 (per-channel sums stay below 2^24). */
+#define CRIM_MAX_PATCH 31
+
+int crim_device_count(void);
+const char* crim_last_error(void);
+
+/* Criminisi_Inpainter.__init__ (:18-38) for one image of H x W: allocates all device state. */
+int crim_create(int H, int W, int patch_size, int device, unsigned flags, crim_t** out);
+/* Same for `batch` independent images of one shape that advance in lock step; replaces the
+ * per-file loop around the constructor in scripts/main.py:44-58. */
+int crim_create_batch(int batch, int H, int W, int patch_size, int device, unsigned flags,
+                      crim_t** out);
+void crim_destroy(crim_t* h);
+
+/* Hands over working_image / working_mask (:29-30) and derives confidence (:35) and all
+ * cached per-pixel fields.  Strides are in bytes; inputs are host memory and are not modified. */
+int crim_upload(crim_t* h, const uint8_t* bgr, ptrdiff_t row_stride, const uint8_t* mask,
+                ptrdiff_t mask_row_stride);
+int crim_upload_batch(crim_t* h, int first, int count, const uint8_t* bgr, ptrdiff_t image_stride,
+                      ptrdiff_t row_stride, const uint8_t* mask, ptrdiff_t mask_image_stride,
+                      ptrdiff_t mask_row_stride);
+/* Same, from dense device buffers ([count][H][W][3] and [count][H][W]) on the engine's GPU. */
+int crim_upload_device(crim_t* h, int first, int count, const void* d_bgr, const void* d_mask);
+
+/* inpaint() (:40-88): runs the loop until every image's mask is empty, or until max_iters
+ * iterations have been executed in this call (max_iters <= 0: no limit).  iters_done receives
+ * the largest per-image iteration count so far, remaining the total masked pixels left. */
+int crim_run(crim_t* h, long max_iters, long* iters_done, long* remaining);
+
+/* working_image (:88), confidence and working_mask after the run; null outputs are skipped. */
+int crim_download(crim_t* h, uint8_t* bgr_out, double* conf_out, uint8_t* mask_out);
+int crim_download_batch(crim_t* h, int first, int count, uint8_t* bgr_out, double* conf_out,
+                        uint8_t* mask_out);
+/* Dense device-side copy of the working images ([count][H][W][3]). */
+int crim_download_device(crim_t* h, int first, int count, void* d_bgr_out);
+
+/* Per-iteration decisions of image `index` (parity instrument; no counterpart in the reference
+ * beyond the values its loop computes at :62-74). */
+int crim_trace(crim_t* h, int index, crim_iter_rec* buf, long cap, long* n);
+/* Iterations executed so far by image `index`. */
+int crim_iterations(crim_t* h, int index, long* n);
+
+/* The integer BGR->Lab tables the engine uses in place of cv2.cvtColor(..., COLOR_BGR2LAB)
+ * (:225): 256-entry sRGB gamma table, 3072-entry cube-root table, 9 matrix coefficients
+ * (row-major X,Y,Z; columns ordered B,G,R). */
+int crim_lab_tables(uint16_t* gamma256, uint16_t* cbrt3072, int32_t* coeffs9);
+
+/* Accumulated HIP-event time of the search kernel (needs CRIM_FLAG_PROFILE) since the last
+ * upload: total milliseconds, number of launches, candidate windows scored per launch summed. */
+int crim_profile(crim_t* h, double* search_ms, long* search_launches, double* evals);
+
+/* Debug/parity: full-frame front (:103), data (:134) and priority (:112) of image `index` for
+ * the iteration that would run next, computed without advancing the loop.  Null outputs are
+ * skipped. */
+int crim_peek_fields(crim_t* h, int index, uint8_t* front_out, double* data_out,
+                     double* priority_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,264 @@
+"""GPU parity tests: the HIP engine, called through the C ABI, against the CPU oracle on the
+same seeded inputs.  Bar: bit-exact -- identical (target, source) per iteration, identical fp64
+cost and confidence, identical output bytes.  (The oracle itself is "parity unpinned" with
+respect to the reference; see oracle/cv2_restated.py.)"""
+import numpy as np
+import pytest
+
+from helpers import golden_cases, load_golden
+
+import crim_hip_capi as capi
+import crim_synth
+from oracle import c_oracle
+from oracle.criminisi_np import CriminisiOracle
+
+pytestmark = pytest.mark.gpu
+
+
+def engine_run(img, mask, p, flags=0, max_iters=0):
+    H, W = mask.shape
+    with capi.Engine(H, W, p, flags=flags) as eng:
+        eng.upload(img, mask)
+        eng.run(max_iters)
+        out, conf, msk = eng.download(want_conf=True, want_mask=True)
+        tr = eng.trace(0)
+    return out[0], conf[0], msk[0], tr
+
+
+def assert_same_as_oracle(img, mask, p, flags=0):
+    out, conf, msk, tr = engine_run(img, mask, p, flags)
+    oout, oconf, omask, otr, n = c_oracle.run(img, mask, p)
+    assert len(tr) == n, "iteration count %d vs oracle %d" % (len(tr), n)
+    for f in ("tr", "tc", "sy", "sx", "remaining"):
+        bad = np.nonzero(tr[f] != otr[f])[0]
+        assert bad.size == 0, "%s differs first at iteration %d: %s vs %s" % (
+            f, bad[0], tr[bad[0]], otr[bad[0]])
+    assert np.array_equal(tr["cost"], otr["cost"])
+    assert np.array_equal(out, oout)
+    assert np.array_equal(conf, oconf)
+    assert not msk.any()
+    return n
+
+
+def rand_case(seed, H, W, noise=True, colour=True, border=False):
+    rng = np.random.default_rng(seed)
+    if noise:
+        img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    else:
+        img = crim_synth.xray_like(H, W, seed, colour=colour)
+    m = np.zeros((H, W), np.uint8)
+    lo = 0 if border else 10
+    for _ in range(3):
+        h = int(rng.integers(3, max(4, H // 4)))
+        w = int(rng.integers(3, max(4, W // 4)))
+        y0 = int(rng.integers(lo, H - lo - h + 1))
+        x0 = int(rng.integers(lo, W - lo - w + 1))
+        m[y0:y0 + h, x0:x0 + w] = 1
+    return img, m
+
+
+@pytest.mark.parametrize("p", [3, 5, 7, 9, 11, 13, 15])
+def test_fast_kernels_interior_mask(p):
+    img, m = rand_case(100 + p, 72, 88, noise=(p % 4 == 1), colour=True)
+    assert_same_as_oracle(img, m, p)
+
+
+@pytest.mark.parametrize("p", [3, 7, 9, 15])
+def test_border_clipped_patches(p):
+    img, m = rand_case(200 + p, 64, 70, noise=False, colour=True, border=True)
+    m[0:6, 0:9] = 1
+    m[-5:, -7:] = 1
+    m[30:36, 0:4] = 1
+    assert_same_as_oracle(img, m, p)
+
+
+@pytest.mark.parametrize("p", [1, 2, 4, 8, 17, 21])
+def test_generic_patch_sizes(p):
+    img, m = rand_case(300 + p, 48, 52, noise=False, colour=(p % 2 == 0), border=(p > 8))
+    assert_same_as_oracle(img, m, p)
+
+
+@pytest.mark.parametrize("p", [5, 9])
+def test_generic_kernel_flag_matches(p):
+    img, m = rand_case(400 + p, 60, 64, noise=False)
+    assert_same_as_oracle(img, m, p, flags=capi.FLAG_GENERIC_SEARCH)
+
+
+def test_eager_mode_matches():
+    img, m = rand_case(450, 60, 64, noise=False)
+    assert_same_as_oracle(img, m, 9, flags=capi.FLAG_EAGER)
+
+
+def test_grey_replicated_image_with_many_ties():
+    # flat regions: data term = 0.001 exactly on many front pixels, cost ties between windows
+    img = np.full((64, 64, 3), 90, np.uint8)
+    img[:, 32:] = 160
+    m = np.zeros((64, 64), np.uint8)
+    m[20:44, 20:44] = 1
+    assert_same_as_oracle(img, m, 9)
+
+
+def test_empty_mask_runs_one_noop_iteration():
+    img = crim_synth.xray_like(40, 40, 5)
+    m = np.zeros((40, 40), np.uint8)
+    out, conf, msk, tr = engine_run(img, m, 9)
+    assert len(tr) == 1 and np.array_equal(out, img) and np.all(conf == 1.0)
+    assert_same_as_oracle(img, m, 9)
+
+
+def test_single_pixel_hole():
+    img = crim_synth.xray_like(40, 40, 6, colour=True)
+    m = np.zeros((40, 40), np.uint8)
+    m[17, 23] = 1
+    assert assert_same_as_oracle(img, m, 9) == 1
+
+
+def test_no_admissible_window_falls_back_to_origin():
+    # every 9x9 window holds a masked pixel: costs are all +inf, argmin is window (0,0)
+    img = np.random.default_rng(3).integers(0, 256, (20, 20, 3), dtype=np.uint8)
+    m = np.zeros((20, 20), np.uint8)
+    m[4::5, 4::5] = 1
+    assert_same_as_oracle(img, m, 9)
+
+
+def test_mask_touching_every_border():
+    img = crim_synth.xray_like(48, 48, 8, colour=True)
+    m = np.zeros((48, 48), np.uint8)
+    m[0, :] = 1
+    m[-1, :] = 1
+    m[:, 0] = 1
+    m[:, -1] = 1
+    m[20:28, 20:28] = 1
+    assert_same_as_oracle(img, m, 9)
+
+
+def test_non_terminating_input_reports_no_progress():
+    # patch_size 1 and a mask on every odd-parity pixel: no known pixel has a masked diagonal
+    # neighbour, so the front is empty, the target falls back to (0,0), whose 1x1 patch is
+    # already known -- the reference loop (:51-83) would spin for ever; the engine reports it.
+    img = np.zeros((16, 16, 3), np.uint8)
+    yy, xx = np.mgrid[0:16, 0:16]
+    m = ((yy + xx) % 2 == 1).astype(np.uint8)
+    with capi.Engine(16, 16, 1) as eng:
+        eng.upload(img, m)
+        with pytest.raises(capi.CriminisiHipError) as ei:
+            eng.run()
+        assert ei.value.code == capi.CRIM_ERR_NO_PROGRESS
+        assert eng.iterations(0) == 1
+
+
+def test_stepping_equals_full_run():
+    img, m = rand_case(500, 56, 60, noise=False)
+    out, conf, msk, tr = engine_run(img, m, 9)
+    with capi.Engine(56, 60, 9) as eng:
+        eng.upload(img, m)
+        steps = 0
+        while True:
+            it, rem = eng.run(max_iters=1)
+            steps += 1
+            assert it == steps
+            if rem == 0:
+                break
+        out2, conf2, _ = eng.download(want_conf=True)
+        tr2 = eng.trace(0)
+    assert steps == len(tr)
+    assert np.array_equal(out, out2[0]) and np.array_equal(conf, conf2[0])
+    assert np.array_equal(tr, tr2)
+
+
+def test_fields_match_numpy_oracle_mid_run():
+    img, m = rand_case(600, 52, 58, noise=False, colour=True)
+    o = CriminisiOracle(img, m, 9)
+    with capi.Engine(52, 58, 9) as eng:
+        eng.upload(img, m)
+        for k in range(4):
+            front, data, prio = eng.peek_fields(0)
+            # oracle: compute the same three fields for its current state without advancing
+            o._find_front()
+            saved = o.confidence.copy()
+            o._update_priorities()
+            assert np.array_equal(front, o.front)
+            fm = o.front > 0
+            assert np.array_equal(data[fm], o.data[fm])
+            assert np.array_equal(prio, o.priority)
+            o.confidence = saved
+            o.step()
+            eng.run(max_iters=1)
+            out, conf, msk = eng.download(want_conf=True, want_mask=True)
+            assert np.array_equal(out[0], o.working_image)
+            assert np.array_equal(conf[0], o.confidence)
+            assert np.array_equal(msk[0], o.working_mask)
+
+
+def test_batch_of_different_masks():
+    H, W, B = 64, 64, 5
+    imgs = np.stack([crim_synth.xray_like(H, W, 700 + i, colour=(i % 2 == 0)) for i in range(B)])
+    masks = np.stack([crim_synth.blob_mask(H, W, 700 + i, fraction=0.04 + 0.03 * i, margin=9)
+                      for i in range(B)])
+    masks[3] = 0            # one image with nothing to do
+    with capi.Engine(H, W, 9, batch=B) as eng:
+        eng.upload(imgs, masks)
+        eng.run()
+        out, conf, msk = eng.download(want_conf=True, want_mask=True)
+        traces = [eng.trace(i) for i in range(B)]
+    for i in range(B):
+        oout, oconf, omask, otr, n = c_oracle.run(imgs[i], masks[i], 9)
+        assert len(traces[i]) == n
+        assert np.array_equal(traces[i], otr.astype(capi.ITER_REC_DTYPE))
+        assert np.array_equal(out[i], oout) and np.array_equal(conf[i], oconf)
+
+
+def test_engine_reuse_after_reupload():
+    H, W = 48, 48
+    with capi.Engine(H, W, 9) as eng:
+        for seed in (801, 802):
+            img = crim_synth.xray_like(H, W, seed, colour=True)
+            m = crim_synth.blob_mask(H, W, seed, fraction=0.08, margin=9)
+            eng.upload(img, m)
+            eng.run()
+            out, conf, _ = eng.download(want_conf=True)
+            oout, oconf, _, otr, n = c_oracle.run(img, m, 9)
+            assert np.array_equal(out[0], oout) and np.array_equal(conf[0], oconf)
+            assert np.array_equal(eng.trace(0), otr.astype(capi.ITER_REC_DTYPE))
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_golden_fixture(name):
+    g = load_golden(name)
+    out, conf, msk, tr = engine_run(g["image"], g["mask"], int(g["patch_size"]))
+    assert len(tr) == len(g["cost"])
+    assert np.array_equal(np.stack([tr["tr"], tr["tc"], tr["sy"], tr["sx"]], 1), g["trace"])
+    assert np.array_equal(tr["cost"], g["cost"])
+    assert np.array_equal(tr["remaining"], g["remaining"])
+    assert np.array_equal(out, g["out"])
+    assert np.array_equal(conf, g["confidence"])
+
+
+def test_shim_class_end_to_end():
+    from src.criminisi_inpainter import Criminisi_Inpainter
+    img = crim_synth.xray_like(64, 64, 901, colour=True)
+    m = crim_synth.blob_mask(64, 64, 901, fraction=0.06, margin=9)
+    img0, m0 = img.copy(), m.copy()
+    ip = Criminisi_Inpainter(img, m, patch_size=9)
+    out = ip.inpaint()
+    oout, oconf, _, otr, n = c_oracle.run(img0, m0, 9)
+    assert out.dtype == np.uint8 and out.shape == (64, 64, 3)
+    assert np.array_equal(out, oout) and np.array_equal(ip.confidence, oconf)
+    assert np.array_equal(img, img0) and np.array_equal(m, m0)      # inputs never mutated
+    assert not ip.working_mask.any() and ip.iterations == n
+    assert ip.front.shape == (64, 64) and not ip.front.any()
+
+
+def test_full_size_properties_256():
+    """BASELINE configs[1] shape: 256x256 grey image, 10 % mask, patch 9 -- oracle parity plus
+    size-independent properties (known pixels untouched, every filled pixel is a copy of a
+    pixel value present in the source region, the loop terminates with an empty mask)."""
+    img = crim_synth.xray_like(256, 256, 1002)
+    m = crim_synth.blob_mask(256, 256, 1002, fraction=0.10, margin=9)
+    out, conf, msk, tr = engine_run(img, m, 9)
+    assert not msk.any() and tr["remaining"][-1] == 0
+    assert np.array_equal(out[m == 0], img[m == 0])
+    assert np.all(np.diff(tr["remaining"]) < 0)
+    oout, oconf, _, otr, n = c_oracle.run(img, m, 9)
+    assert n == len(tr) and np.array_equal(out, oout) and np.array_equal(conf, oconf)
+    assert np.array_equal(tr, otr.astype(capi.ITER_REC_DTYPE))
