@@ -185,9 +185,16 @@ static void launch_search(crim_engine* h, hipStream_t s) {
 static bool has_fast_search(int P) { return P >= 3 && P <= 15 && (P & 1); }
 
 // One iteration of criminisi_inpainter.py:51-83 as four dependent launches.
+static void launch_tiles(crim_engine* h, hipStream_t s) {
+    const Params& p = h->prm;
+    hipLaunchKernelGGL(k_tiles, dim3(p.B), dim3(256), 0, s, p);
+}
+
+#define TILE_REBUILD_PERIOD 16
+
 static void launch_iteration(crim_engine* h, hipStream_t s, bool profile) {
     const Params& p = h->prm;
-    hipLaunchKernelGGL(k_priority, dim3(p.ptnx, p.ptny, p.B), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(k_priority, dim3(p.pgrid, p.B), dim3(256), 0, s, p);
     hipLaunchKernelGGL(k_select, dim3(p.B), dim3(256), 0, s, p);
     if (profile) (void)hipEventRecord(h->ev[2 * h->ev_used], s);
     launch_search(h, s);
@@ -198,7 +205,10 @@ static void launch_iteration(crim_engine* h, hipStream_t s, bool profile) {
 static int build_graph(crim_engine* h, int iters, GraphSet* out) {
     hipGraph_t graph = nullptr;
     HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-    for (int i = 0; i < iters; ++i) launch_iteration(h, h->stream, false);
+    for (int i = 0; i < iters; ++i) {
+        if (iters > 1 && i % TILE_REBUILD_PERIOD == 0) launch_tiles(h, h->stream);
+        launch_iteration(h, h->stream, false);
+    }
     HIP_TRY(hipStreamEndCapture(h->stream, &graph));
     hipGraphExec_t exec = nullptr;
     hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
@@ -233,7 +243,7 @@ extern "C" void crim_destroy(crim_t* h) {
     for (auto e : h->ev) (void)hipEventDestroy(e);
     Params& p = h->prm;
     void* bufs[] = {p.bgr, p.planes, p.mask, p.grey, p.grad, p.conf, p.invalid, p.tilecnt, p.st,
-                    p.desc, p.plist, p.slist, p.trace, h->d_bbox, h->d_gamma, h->d_cbrt, h->d_peek};
+                    p.desc, p.tlist, p.ntiles, p.plist, p.slist, p.trace, h->d_bbox, h->d_gamma, h->d_cbrt, h->d_peek};
     for (void* q : bufs)
         if (q) (void)hipFree(q);
     if (h->h_state) (void)hipHostFree(h->h_state);
@@ -293,7 +303,10 @@ extern "C" int crim_create_batch(int batch, int H, int W, int patch_size, int de
     alloc((void**)&p.tilecnt, Bz * p.tnx * p.tny * sizeof(int));
     alloc((void**)&p.st, Bz * sizeof(ImgState));
     alloc((void**)&p.desc, Bz * sizeof(Desc));
-    alloc((void**)&p.plist, Bz * p.tnx * p.tny * sizeof(PEntry));
+    p.pgrid = std::min(p.tnx * p.tny, std::max(8, 4096 / batch));
+    alloc((void**)&p.tlist, Bz * p.tnx * p.tny * sizeof(int));
+    alloc((void**)&p.ntiles, Bz * sizeof(int));
+    alloc((void**)&p.plist, Bz * p.pgrid * sizeof(PEntry));
     alloc((void**)&p.slist, Bz * p.snx * p.sny * sizeof(SEntry));
     alloc((void**)&h->d_bbox, Bz * 4 * sizeof(int));
     alloc((void**)&h->d_gamma, sizeof(t.gamma));
@@ -464,6 +477,7 @@ extern "C" int crim_run(crim_t* h, long max_iters, long* iters_done, long* remai
     const bool eager = (h->flags & CRIM_FLAG_EAGER) != 0;
     long done = 0;
     int rc = CRIM_OK;
+    launch_tiles(h, h->stream);
     for (;;) {
         HIP_TRY(hipMemcpyAsync(h->h_state, p.st, (size_t)p.B * sizeof(ImgState), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
@@ -486,6 +500,7 @@ extern "C" int crim_run(crim_t* h, long max_iters, long* iters_done, long* remai
             // one iteration per round so that the number of live images per launch is known
             const double evals = (double)live * (double)std::max(p.H - p.P + 1, 0) * (double)std::max(p.W - p.P + 1, 0);
             h->ev_evals[h->ev_used] = evals;
+            if (done % TILE_REBUILD_PERIOD == 0) launch_tiles(h, h->stream);
             launch_iteration(h, h->stream, true);
             ++h->ev_used;
             if (h->ev_used == (int)h->ev_evals.size()) {
@@ -494,7 +509,10 @@ extern "C" int crim_run(crim_t* h, long max_iters, long* iters_done, long* remai
             }
             done += 1;
         } else if (eager) {
-            for (long i = 0; i < need; ++i) launch_iteration(h, h->stream, false);
+            for (long i = 0; i < need; ++i) {
+                if ((done + i) % TILE_REBUILD_PERIOD == 0) launch_tiles(h, h->stream);
+                launch_iteration(h, h->stream, false);
+            }
             done += need;
         } else {
             long left = need;
@@ -616,7 +634,7 @@ extern "C" int crim_peek_fields(crim_t* h, int index, uint8_t* front_out, double
     double* d_data = (double*)h->d_peek;
     double* d_prio = d_data + HW;
     uint8_t* d_front = (uint8_t*)(d_prio + HW);
-    hipLaunchKernelGGL(k_fields, dim3(p.tnx, p.tny), dim3(256), 0, h->stream, p, index, d_front, d_data, d_prio);
+    hipLaunchKernelGGL(k_fields, dim3(p.tnx, (p.H + 1) / 2), dim3(256), 0, h->stream, p, index, d_front, d_data, d_prio);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (front_out) HIP_TRY(hipMemcpy(front_out, d_front, HW, hipMemcpyDeviceToHost));

@@ -108,20 +108,58 @@ struct FrontEval {
     double cnew, data, prio;
 };
 
+#define PG 8   // lanes that cooperate on one front pixel
+
+// NumPy pairwise leaf (n <= 128) computed by PG = 8 cooperating lanes: lane j owns NumPy's
+// accumulator j; the accumulators are combined in NumPy's order by an xor butterfly (floating
+// point addition is commutative, so both partners of an exchange get identical bits).  Every
+// lane returns the full sum.
+__device__ __forceinline__ double pw_leaf8(const PatchReader& a, int lo, int n, int l) {
+    if (n < 8) {
+        double r = -0.0;
+        for (int i = 0; i < n; ++i) r += a(lo + i);
+        return r;
+    }
+    const int lim = n - (n % 8);
+    double r = a(lo + l);
+    for (int i = 8; i < lim; i += 8) r += a(lo + i + l);
+    r = r + __shfl_xor(r, 1, PG);
+    r = r + __shfl_xor(r, 2, PG);
+    r = r + __shfl_xor(r, 4, PG);
+    for (int i = lim; i < n; ++i) r += a(lo + i);
+    return r;
+}
+template <int D>
+__device__ __forceinline__ double pw_sum8(const PatchReader& a, int lo, int n, int l) {
+    if (n <= 128) return pw_leaf8(a, lo, n, l);
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    const double x = pw_sum8<D - 1>(a, lo, n2, l);
+    const double y = pw_sum8<D - 1>(a, lo + n2, n - n2, l);
+    return x + y;
+}
+template <>
+__device__ __forceinline__ double pw_sum8<0>(const PatchReader& a, int lo, int n, int l) {
+    return pw_leaf8(a, lo, n, l);
+}
+
 // Confidence (criminisi_inpainter.py:114-127), data term (:129-214) and priority (:112) of one
-// front pixel.  ccur is the confidence map before this iteration's update.
+// front pixel, computed by PG cooperating lanes (l = lane index within the group; all PG lanes
+// must call this together and all receive the result).  ccur is the confidence map before
+// this iteration's update.
 __device__ __forceinline__ FrontEval eval_front_pixel(const Params& p, const int* grad,
                                                       const double* ccur, int y, int x, int F,
-                                                      const int nb[9]) {
+                                                      const int nb[9], int l) {
     const int H = p.H, W = p.W, half = p.half;
     const int r0 = imax(0, y - half), r1 = imin(y + half, H - 1);
     const int c0 = imax(0, x - half), c1 = imin(x + half, W - 1);
     const int ph = r1 - r0 + 1, pw = c1 - c0 + 1;
+    const int n = ph * pw;
     PatchReader rd;
     rd.c = ccur; rd.W = W; rd.r0 = r0; rd.c0 = c0; rd.pw = pw;
     rd.inv = (65536u + (unsigned)pw - 1u) / (unsigned)pw;
     FrontEval out;
-    out.cnew = pw_sum<3>(rd, 0, ph * pw) / (double)p.psq;
+    out.cnew = pw_sum8<3>(rd, 0, n, l) / (double)p.psq;
 
     // mask normal (:138-164): Sobel/4 correlation, then normalised
     const double a = nb[0], b = nb[1], c = nb[2], d = nb[3], f = nb[5], g = nb[6], h = nb[7],
@@ -134,16 +172,25 @@ __device__ __forceinline__ FrontEval eval_front_pixel(const Params& p, const int
 
     // first maximum of the gradient magnitude inside the patch (:183-211).  grad holds
     // (2*gy, 2*gx) as integers; comparing 4*|g|^2 orders exactly like comparing sqrt(|g|^2).
-    int best = -1, by = 0, bx = 0;
-    for (int rr = r0; rr <= r1; ++rr) {
-        const int* grow = grad + (size_t)rr * W;
-        for (int cc = c0; cc <= c1; ++cc) {
-            const int gpk = grow[cc];
-            const int gy2 = (int)(short)(gpk & 0xffff), gx2 = gpk >> 16;
-            const int m = gy2 * gy2 + gx2 * gx2;
-            if (m > best) { best = m; by = gy2; bx = gx2; }
-        }
+    // Lane l scans elements l, l+8, ... of the flattened patch; the group keeps the largest
+    // magnitude and, among equals, the smallest flattened index.
+    int best = -1, beste = 0x7fffffff, bpk = 0;
+    for (int e = l; e < n; e += PG) {
+        const unsigned q = ((unsigned)e * rd.inv) >> 16;
+        const int col = e - (int)q * pw;
+        const int gpk = grad[(size_t)(r0 + (int)q) * W + c0 + col];
+        const int gy2 = (int)(short)(gpk & 0xffff), gx2 = gpk >> 16;
+        const int m = gy2 * gy2 + gx2 * gx2;
+        if (m > best) { best = m; beste = e; bpk = gpk; }
     }
+#pragma unroll
+    for (int off = 1; off < PG; off <<= 1) {
+        const int om = __shfl_xor(best, off, PG);
+        const int oe = __shfl_xor(beste, off, PG);
+        const int ok = __shfl_xor(bpk, off, PG);
+        if (om > best || (om == best && oe < beste)) { best = om; beste = oe; bpk = ok; }
+    }
+    const int by = (int)(short)(bpk & 0xffff), bx = bpk >> 16;
     const double Gy = (double)by * 0.5, Gx = (double)bx * 0.5;
     const double t0 = ux * Gy, t1 = uy * Gx;
     out.data = sqrt(t0 * t0 + t1 * t1) + 0.001;
@@ -273,70 +320,106 @@ __device__ __forceinline__ bool better_prio(double pa, int ia, double pb, int ib
     return pa > pb || (pa == pb && ia < ib);
 }
 
-__global__ __launch_bounds__(256) void k_priority(Params p) {
-    const int b = blockIdx.z;
-    ImgState* st = p.st + b;
-    if (!st->live) return;
-    const int tX = p.ptx0 + blockIdx.x, tY = p.pty0 + blockIdx.y;
-    const int H = p.H, W = p.W;
-    const size_t HW = (size_t)H * W;
-
-    // A tile can hold front pixels only if it or a neighbouring tile holds masked pixels.
-    const int* tcnt = p.tilecnt + (size_t)b * p.tny * p.tnx;
+// Is tile (tX, tY) worth scanning: masked pixels in its 3x3 tile neighbourhood (a front pixel is
+// a known pixel with a masked diagonal neighbour), or overlap with the previous patch box grown
+// by one pixel (confidence buffer fix-up, see k_priority).
+__device__ __forceinline__ bool tile_active(const Params& p, const int* tcnt, const ImgState* st,
+                                            int tX, int tY, bool* fix_out) {
     int nbsum = 0;
     for (int dy = -1; dy <= 1; ++dy)
         for (int dx = -1; dx <= 1; ++dx) {
             const int yy = tY + dy, xx = tX + dx;
             if (yy >= 0 && yy < p.tny && xx >= 0 && xx < p.tnx) nbsum += tcnt[yy * p.tnx + xx];
         }
-    // Pixels written to the current confidence buffer by the previous iteration (its front and
-    // its filled patch) that are not rewritten now must be carried over to the other buffer;
-    // all of them lie within one pixel of the previous patch box.
-    const int has_fix = st->has_fix;
     const int fr0 = st->fix_r0 - 1, fr1 = st->fix_r1 + 1, fc0 = st->fix_c0 - 1, fc1 = st->fix_c1 + 1;
-    const bool fix_tile = has_fix && tY * CRIM_TILE <= fr1 && tY * CRIM_TILE + CRIM_TILE - 1 >= fr0 &&
-                          tX * CRIM_TILE <= fc1 && tX * CRIM_TILE + CRIM_TILE - 1 >= fc0;
-    if (nbsum == 0 && !fix_tile) return;
+    const bool fix = st->has_fix && tY * CRIM_TILE <= fr1 && tY * CRIM_TILE + CRIM_TILE - 1 >= fr0 &&
+                     tX * CRIM_TILE <= fc1 && tX * CRIM_TILE + CRIM_TILE - 1 >= fc0;
+    *fix_out = fix;
+    return nbsum != 0 || fix;
+}
 
+// Rebuilds the per-image list of tiles the priority scan must visit.  The mask only shrinks, so
+// a list stays a valid superset until the next rebuild; the scan re-checks every tile anyway.
+__global__ __launch_bounds__(256) void k_tiles(Params p) {
+    const int b = blockIdx.x;
+    const ImgState* st = p.st + b;
+    if (!st->live) return;
+    __shared__ int s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const int* tcnt = p.tilecnt + (size_t)b * p.tny * p.tnx;
+    int* tl = p.tlist + (size_t)b * p.tnx * p.tny;
+    for (int i = threadIdx.x; i < p.ptnx * p.ptny; i += 256) {
+        const int tX = p.ptx0 + i % p.ptnx, tY = p.pty0 + i / p.ptnx;
+        bool fix;
+        if (tile_active(p, tcnt, st, tX, tY, &fix)) tl[atomicAdd(&s_n, 1)] = tY * p.tnx + tX;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) p.ntiles[b] = s_n;
+}
+
+// grid (pgrid, B): block g of image b walks tiles g, g + pgrid, ... of that image's tile list.
+__global__ __launch_bounds__(256) void k_priority(Params p) {
+    const int b = blockIdx.y;
+    ImgState* st = p.st + b;
+    if (!st->live) return;
+    const int H = p.H, W = p.W;
+    const size_t HW = (size_t)H * W;
+    const int ntiles = p.ntiles[b];
+    if ((int)blockIdx.x >= ntiles) return;
+    const int* tl = p.tlist + (size_t)b * p.tnx * p.tny;
+    const int* tcnt = p.tilecnt + (size_t)b * p.tny * p.tnx;
     const int cur = st->cur;
     const double* ccur = p.conf + ((size_t)b * 2 + cur) * HW;
     double* cnxt = p.conf + ((size_t)b * 2 + (cur ^ 1)) * HW;
     const uint8_t* mask = p.mask + b * HW;
     const int* grad = p.grad + b * HW;
+    // Pixels written to the current confidence buffer by the previous iteration (its front and
+    // its filled patch) that are not rewritten now must be carried over to the other buffer;
+    // all of them lie within one pixel of the previous patch box.
+    const int fr0 = st->fix_r0 - 1, fr1 = st->fix_r1 + 1, fc0 = st->fix_c0 - 1, fc1 = st->fix_c1 + 1;
 
     __shared__ int s_n;
     __shared__ int s_list[256];
     __shared__ double s_bp[4];
     __shared__ int s_bi[4];
     const int tid = threadIdx.x;
-    if (tid == 0) s_n = 0;
-    __syncthreads();
-
-    const int y = tY * CRIM_TILE + (tid >> 4), x = tX * CRIM_TILE + (tid & 15);
-    int nb[9];
-    int F = 0;
-    if (y < H && x < W) {
-        F = front_weight(mask, H, W, y, x, nb);
-        if (F == 0 && fix_tile && y >= fr0 && y <= fr1 && x >= fc0 && x <= fc1)
-            cnxt[(size_t)y * W + x] = ccur[(size_t)y * W + x];
-    }
-    if (F > 0) s_list[atomicAdd(&s_n, 1)] = tid;
-    __syncthreads();
-    const int n = s_n;
-
+    const int grp = tid / PG, l = tid % PG;
     double bestP = -1.0;
     int bestI = 0x7fffffff;
-    if (tid < n) {
-        const int t = s_list[tid];
-        const int fy = tY * CRIM_TILE + (t >> 4), fx = tX * CRIM_TILE + (t & 15);
-        int fnb[9];
-        const int fF = front_weight(mask, H, W, fy, fx, fnb);
-        const FrontEval ev = eval_front_pixel(p, grad, ccur, fy, fx, fF, fnb);
-        cnxt[(size_t)fy * W + fx] = ev.cnew;
-        bestP = ev.prio;
-        bestI = fy * W + fx;
+
+    for (int ti = blockIdx.x; ti < ntiles; ti += gridDim.x) {
+        const int tile = tl[ti];
+        const int tY = tile / p.tnx, tX = tile - tY * p.tnx;
+        bool fix_tile;
+        if (!tile_active(p, tcnt, st, tX, tY, &fix_tile)) continue;   // block-uniform
+        if (tid == 0) s_n = 0;
+        __syncthreads();
+        const int y = tY * CRIM_TILE + (tid >> 4), x = tX * CRIM_TILE + (tid & 15);
+        int nb[9];
+        int F = 0;
+        if (y < H && x < W) {
+            F = front_weight(mask, H, W, y, x, nb);
+            if (F == 0 && fix_tile && y >= fr0 && y <= fr1 && x >= fc0 && x <= fc1)
+                cnxt[(size_t)y * W + x] = ccur[(size_t)y * W + x];
+        }
+        if (F > 0) s_list[atomicAdd(&s_n, 1)] = tid;
+        __syncthreads();
+        const int n = s_n;
+        for (int e = grp; e < n; e += 256 / PG) {
+            const int t = s_list[e];
+            const int fy = tY * CRIM_TILE + (t >> 4), fx = tX * CRIM_TILE + (t & 15);
+            int fnb[9];
+            const int fF = front_weight(mask, H, W, fy, fx, fnb);
+            const FrontEval ev = eval_front_pixel(p, grad, ccur, fy, fx, fF, fnb, l);
+            if (l == 0) {
+                cnxt[(size_t)fy * W + fx] = ev.cnew;
+                const int pos = fy * W + fx;
+                if (better_prio(ev.prio, pos, bestP, bestI)) { bestP = ev.prio; bestI = pos; }
+            }
+        }
+        __syncthreads();   // s_n / s_list are reused by the next tile
     }
-    if (n == 0) return;
     // block arg-max: highest priority, lowest row-major index on ties (np.argmax, :217)
     for (int off = 32; off > 0; off >>= 1) {
         const double op = __shfl_down(bestP, off);
@@ -352,7 +435,7 @@ __global__ __launch_bounds__(256) void k_priority(Params p) {
             const unsigned k = atomicAdd(&st->pcount, 1u);
             PEntry e;
             e.prio = bestP; e.pos = bestI; e.pad = 0;
-            p.plist[(size_t)b * p.ptnx * p.ptny + k] = e;
+            p.plist[(size_t)b * p.pgrid + k] = e;
         }
     }
 }
@@ -361,8 +444,10 @@ __global__ __launch_bounds__(256) void k_priority(Params p) {
 // instrument): same arithmetic as k_priority, no state is changed.
 __global__ __launch_bounds__(256) void k_fields(Params p, int b, uint8_t* front, double* data,
                                                 double* prio) {
-    const int y = blockIdx.y * CRIM_TILE + (threadIdx.x >> 4);
-    const int x = blockIdx.x * CRIM_TILE + (threadIdx.x & 15);
+    // PG lanes per pixel: a block covers 32 pixels of one tile row pair
+    const int l = threadIdx.x % PG, px = threadIdx.x / PG;
+    const int y = blockIdx.y * 2 + (px >> 4);
+    const int x = blockIdx.x * CRIM_TILE + (px & 15);
     if (y >= p.H || x >= p.W) return;
     const size_t HW = (size_t)p.H * p.W;
     const ImgState* st = p.st + b;
@@ -370,15 +455,17 @@ __global__ __launch_bounds__(256) void k_fields(Params p, int b, uint8_t* front,
     int nb[9];
     const int F = front_weight(p.mask + b * HW, p.H, p.W, y, x, nb);
     const size_t i = (size_t)y * p.W + x;
-    if (front) front[i] = (uint8_t)F;
     double dv = 0.001, pv = 0.0;   // off the front the gradient is zero: sqrt(0) + 0.001
     if (F > 0) {
-        const FrontEval ev = eval_front_pixel(p, p.grad + b * HW, ccur, y, x, F, nb);
+        const FrontEval ev = eval_front_pixel(p, p.grad + b * HW, ccur, y, x, F, nb, l);
         dv = ev.data;
         pv = ev.prio;
     }
-    if (data) data[i] = dv;
-    if (prio) prio[i] = pv;
+    if (l == 0) {
+        if (front) front[i] = (uint8_t)F;
+        if (data) data[i] = dv;
+        if (prio) prio[i] = pv;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -404,7 +491,7 @@ __global__ __launch_bounds__(256) void k_select(Params p) {
     __shared__ int s_soff;
 
     const unsigned n = st->pcount;
-    const PEntry* pl = p.plist + (size_t)b * p.ptnx * p.ptny;
+    const PEntry* pl = p.plist + (size_t)b * p.pgrid;
     double bestP = -1.0;
     int bestI = 0x7fffffff;
     for (unsigned i = tid; i < n; i += 256) {
@@ -560,8 +647,10 @@ __global__ __launch_bounds__(256) void k_search(Params p) {
     constexpr int ND = (P + 6) / 4;
     constexpr int R = SB_R;
     constexpr int LROWS = SB_H + P - 1;
-    constexpr int LCOLS = SB_TXG + ND - 1;
-    __shared__ uint32_t lds[5][LROWS][LCOLS];
+    constexpr int LC4 = (SB_TXG + ND - 1 + 3) / 4;   // 16-byte chunks per staged row
+    constexpr int LCOLS = LC4 * 4;
+    constexpr int NCHUNK = 5 * LROWS * LC4;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[5][LROWS][LCOLS];
     __shared__ double s_c[4];
     __shared__ unsigned s_i[4];
     __shared__ int s_bound;
@@ -603,17 +692,28 @@ __global__ __launch_bounds__(256) void k_search(Params p) {
     }
     if (!__syncthreads_or(vbits != 0)) return;
 
-    // stage the five byte planes of this tile (zero beyond the image)
+    // stage the five byte planes of this tile (zero beyond the image): 16-byte chunks, all of a
+    // thread's loads issued before the first LDS store
     const uint8_t* pl = p.planes + (size_t)b * 5 * H * p.Wp;
-    uint32_t* lflat = &lds[0][0][0];
-    for (int idx = tid; idx < 5 * LROWS * LCOLS; idx += 256) {
-        const int pln = idx / (LROWS * LCOLS);
-        const int rem = idx - pln * (LROWS * LCOLS);
-        const int row = rem / LCOLS, col = rem - row * LCOLS;
-        const int gy = y0 + row, gx = x0 + 4 * col;
-        uint32_t v = 0;
-        if (gy < H && gx < p.Wp) v = *(const uint32_t*)(pl + ((size_t)pln * H + gy) * p.Wp + gx);
-        lflat[idx] = v;
+    {
+        constexpr int NIT = (NCHUNK + 255) / 256;
+        uint4 v[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int c = tid + k * 256;
+            const int pln = c / (LROWS * LC4);
+            const int rem = c - pln * (LROWS * LC4);
+            const int row = rem / LC4, c4 = rem - row * LC4;
+            const int gy = y0 + row, gx = x0 + 16 * c4;
+            v[k] = make_uint4(0, 0, 0, 0);
+            if (c < NCHUNK && gy < H && gx + 16 <= p.Wp)
+                v[k] = *(const uint4*)(pl + ((size_t)pln * H + gy) * p.Wp + gx);
+        }
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int c = tid + k * 256;
+            if (c < NCHUNK) ((uint4*)&lds[0][0][0])[c] = v[k];
+        }
     }
     __syncthreads();
 

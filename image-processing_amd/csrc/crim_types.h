@@ -75,6 +75,7 @@ struct Params {
     int tnx, tny; // priority tile grid over the whole image
     int ptx0, pty0, ptnx, ptny;  // tile window the priority scan covers
     int snx, sny; // search block grid
+    int pgrid;    // priority-scan blocks per image
     int generic;  // use the unspecialised search kernel
     long trace_cap;
     uint8_t* bgr;      // [B][H][W][3]
@@ -87,7 +88,9 @@ struct Params {
     int* tilecnt;      // [B][tny][tnx] masked pixels per tile
     ImgState* st;
     Desc* desc;
-    PEntry* plist;     // [B][ptnx*ptny]
+    int* tlist;        // [B][tnx*tny] tiles the priority scan visits
+    int* ntiles;       // [B]
+    PEntry* plist;     // [B][pgrid]
     SEntry* slist;     // [B][snx*sny]
     crim_iter_rec* trace;  // [B][trace_cap]
     const uint16_t* gamma_tab;
