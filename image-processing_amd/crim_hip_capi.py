@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcriminisi_hip.so")
+# CRIM_HIP_LIB points at an alternative build of the same library (diagnostic builds)
+LIB_PATH = os.environ.get("CRIM_HIP_LIB") or os.path.join(_HERE, "lib", "libcriminisi_hip.so")
 
 CRIM_OK = 0
 CRIM_ERR_ARG = 1

@@ -141,7 +141,6 @@ struct crim_engine {
     int patch_size = 0;
     Params prm;
     hipStream_t stream = nullptr;
-    int* d_bbox = nullptr;          // [B][4] ymin, ymax, xmin, xmax of each uploaded mask
     uint16_t* d_gamma = nullptr;
     uint16_t* d_cbrt = nullptr;
     ImgState* h_state = nullptr;    // pinned mirror of prm.st
@@ -185,12 +184,13 @@ static void launch_search(crim_engine* h, hipStream_t s) {
 static bool has_fast_search(int P) { return P >= 3 && P <= 15 && (P & 1); }
 
 // One iteration of criminisi_inpainter.py:51-83 as four dependent launches.
-static void launch_tiles(crim_engine* h, hipStream_t s) {
+// Front-list compaction: stale entries only cost a skipped lookup, so it runs rarely.
+static void launch_compact(crim_engine* h, hipStream_t s) {
     const Params& p = h->prm;
-    hipLaunchKernelGGL(k_tiles, dim3(p.B), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(k_compact, dim3(p.B), dim3(1024), 0, s, p);
 }
 
-#define TILE_REBUILD_PERIOD 16
+#define COMPACT_PERIOD 16
 
 static void launch_iteration(crim_engine* h, hipStream_t s, bool profile) {
     const Params& p = h->prm;
@@ -206,7 +206,7 @@ static int build_graph(crim_engine* h, int iters, GraphSet* out) {
     hipGraph_t graph = nullptr;
     HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     for (int i = 0; i < iters; ++i) {
-        if (iters > 1 && i % TILE_REBUILD_PERIOD == 0) launch_tiles(h, h->stream);
+        if (i > 0 && i % COMPACT_PERIOD == 0) launch_compact(h, h->stream);
         launch_iteration(h, h->stream, false);
     }
     HIP_TRY(hipStreamEndCapture(h->stream, &graph));
@@ -242,8 +242,8 @@ extern "C" void crim_destroy(crim_t* h) {
     free_graphs(h);
     for (auto e : h->ev) (void)hipEventDestroy(e);
     Params& p = h->prm;
-    void* bufs[] = {p.bgr, p.planes, p.mask, p.grey, p.grad, p.conf, p.invalid, p.tilecnt, p.st,
-                    p.desc, p.tlist, p.ntiles, p.plist, p.slist, p.trace, h->d_bbox, h->d_gamma, h->d_cbrt, h->d_peek};
+    void* bufs[] = {p.bgr, p.planes, p.mask, p.grey, p.grad, p.conf, p.invalid, p.flist, p.st,
+                    p.desc, p.plist, p.slist, p.trace, p.dbg, h->d_gamma, h->d_cbrt, h->d_peek};
     for (void* q : bufs)
         if (q) (void)hipFree(q);
     if (h->h_state) (void)hipHostFree(h->h_state);
@@ -280,7 +280,6 @@ extern "C" int crim_create_batch(int batch, int H, int W, int patch_size, int de
     p.Wi = round_up(W, 4) + 4;
     p.tnx = (W + CRIM_TILE - 1) / CRIM_TILE;
     p.tny = (H + CRIM_TILE - 1) / CRIM_TILE;
-    p.ptx0 = 0; p.pty0 = 0; p.ptnx = p.tnx; p.ptny = p.tny;
     // the candidate grid is largest for the most clipped patch: (H - half) x (W - half)
     p.snx = (std::max(W - p.half, 1) + SB_W - 1) / SB_W;
     p.sny = (std::max(H - p.half, 1) + SB_H - 1) / SB_H;
@@ -300,15 +299,14 @@ extern "C" int crim_create_batch(int batch, int H, int W, int patch_size, int de
     alloc((void**)&p.grad, Bz * HW * sizeof(int));
     alloc((void**)&p.conf, Bz * 2 * HW * sizeof(double));
     alloc((void**)&p.invalid, Bz * H * p.Wi);
-    alloc((void**)&p.tilecnt, Bz * p.tnx * p.tny * sizeof(int));
+    p.fcap = (long)HW;
+    alloc((void**)&p.flist, Bz * 2 * HW * sizeof(int));
     alloc((void**)&p.st, Bz * sizeof(ImgState));
     alloc((void**)&p.desc, Bz * sizeof(Desc));
-    p.pgrid = std::min(p.tnx * p.tny, std::max(8, 4096 / batch));
-    alloc((void**)&p.tlist, Bz * p.tnx * p.tny * sizeof(int));
-    alloc((void**)&p.ntiles, Bz * sizeof(int));
+    p.pgrid = std::min(1024, std::max(8, 4096 / batch));
     alloc((void**)&p.plist, Bz * p.pgrid * sizeof(PEntry));
     alloc((void**)&p.slist, Bz * p.snx * p.sny * sizeof(SEntry));
-    alloc((void**)&h->d_bbox, Bz * 4 * sizeof(int));
+    alloc((void**)&p.dbg, 64 * sizeof(long long));
     alloc((void**)&h->d_gamma, sizeof(t.gamma));
     alloc((void**)&h->d_cbrt, sizeof(t.cbrt_));
     if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_state, Bz * sizeof(ImgState), hipHostMallocDefault);
@@ -318,6 +316,7 @@ extern "C" int crim_create_batch(int batch, int H, int W, int patch_size, int de
     if (e == hipSuccess) e = hipMemset(p.planes, 0, Bz * 5 * H * p.Wp);
     if (e == hipSuccess) e = hipMemset(p.invalid, 1, Bz * H * p.Wi);
     if (e == hipSuccess) e = hipMemset(p.st, 0, Bz * sizeof(ImgState));
+    if (e == hipSuccess) e = hipMemset(p.dbg, 0, 64 * sizeof(long long));
     if (e == hipSuccess) e = hipMemset(p.desc, 0, Bz * sizeof(Desc));
     if (e != hipSuccess) {
         const int code = fail(e == hipErrorOutOfMemory ? CRIM_ERR_NOMEM : CRIM_ERR_HIP,
@@ -344,9 +343,9 @@ extern "C" int crim_create(int H, int W, int patch_size, int device, unsigned fl
 // Derives every cached field of images [first, first+count) from prm.bgr / prm.mask.
 static int init_images(crim_engine* h, int first, int count) {
     const Params& p = h->prm;
-    hipLaunchKernelGGL(k_init_state, dim3((count + 63) / 64), dim3(64), 0, h->stream, p, first, count, h->d_bbox);
+    hipLaunchKernelGGL(k_init_state, dim3((count + 63) / 64), dim3(64), 0, h->stream, p, first, count);
     dim3 grid(p.tnx, p.tny, count), block(256);
-    hipLaunchKernelGGL(k_init_pixels, grid, block, 0, h->stream, p, first, h->d_bbox);
+    hipLaunchKernelGGL(k_init_pixels, grid, block, 0, h->stream, p, first);
     hipLaunchKernelGGL(k_init_fields, grid, block, 0, h->stream, p, first);
     HIP_TRY(hipGetLastError());
     for (int i = 0; i < count; ++i) h->uploaded[first + i] = true;
@@ -400,31 +399,14 @@ extern "C" int crim_upload_device(crim_t* h, int first, int count, const void* d
     return init_images(h, first, count);
 }
 
-// Sizes the priority scan window and the trace buffer from what was uploaded, then (re)builds
-// the iteration graphs.
+// Sizes the trace buffer from what was uploaded, then (re)builds the iteration graphs.
 static int prepare(crim_engine* h) {
     Params& p = h->prm;
     for (int i = 0; i < p.B; ++i)
         if (!h->uploaded[i]) return fail(CRIM_ERR_STATE, "crim_run: image %d was never uploaded", i);
-    int bbox[4] = {0x7fffffff, -1, 0x7fffffff, -1};
-    std::vector<int> bb((size_t)p.B * 4);
     HIP_TRY(hipMemcpyAsync(h->h_state, p.st, (size_t)p.B * sizeof(ImgState), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    HIP_TRY(hipMemcpy(bb.data(), h->d_bbox, bb.size() * sizeof(int), hipMemcpyDeviceToHost));
-    for (int i = 0; i < p.B; ++i) {
-        bbox[0] = std::min(bbox[0], bb[4 * i]); bbox[1] = std::max(bbox[1], bb[4 * i + 1]);
-        bbox[2] = std::min(bbox[2], bb[4 * i + 2]); bbox[3] = std::max(bbox[3], bb[4 * i + 3]);
-    }
     Params q = p;
-    if (bbox[1] >= bbox[0] && bbox[3] >= bbox[2]) {
-        // front pixels lie within one pixel of a masked pixel
-        const int y0 = std::max(bbox[0] - 1, 0), y1 = std::min(bbox[1] + 1, p.H - 1);
-        const int x0 = std::max(bbox[2] - 1, 0), x1 = std::min(bbox[3] + 1, p.W - 1);
-        q.pty0 = y0 / CRIM_TILE; q.ptny = y1 / CRIM_TILE - q.pty0 + 1;
-        q.ptx0 = x0 / CRIM_TILE; q.ptnx = x1 / CRIM_TILE - q.ptx0 + 1;
-    } else {
-        q.ptx0 = q.pty0 = 0; q.ptnx = q.ptny = 1;
-    }
     long need = 1;
     for (int i = 0; i < p.B; ++i) need = std::max(need, (long)h->h_state[i].remaining + 1);
     if (need > p.trace_cap || !p.trace) {
@@ -477,7 +459,6 @@ extern "C" int crim_run(crim_t* h, long max_iters, long* iters_done, long* remai
     const bool eager = (h->flags & CRIM_FLAG_EAGER) != 0;
     long done = 0;
     int rc = CRIM_OK;
-    launch_tiles(h, h->stream);
     for (;;) {
         HIP_TRY(hipMemcpyAsync(h->h_state, p.st, (size_t)p.B * sizeof(ImgState), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
@@ -500,7 +481,7 @@ extern "C" int crim_run(crim_t* h, long max_iters, long* iters_done, long* remai
             // one iteration per round so that the number of live images per launch is known
             const double evals = (double)live * (double)std::max(p.H - p.P + 1, 0) * (double)std::max(p.W - p.P + 1, 0);
             h->ev_evals[h->ev_used] = evals;
-            if (done % TILE_REBUILD_PERIOD == 0) launch_tiles(h, h->stream);
+            if (done > 0 && done % COMPACT_PERIOD == 0) launch_compact(h, h->stream);
             launch_iteration(h, h->stream, true);
             ++h->ev_used;
             if (h->ev_used == (int)h->ev_evals.size()) {
@@ -510,7 +491,7 @@ extern "C" int crim_run(crim_t* h, long max_iters, long* iters_done, long* remai
             done += 1;
         } else if (eager) {
             for (long i = 0; i < need; ++i) {
-                if ((done + i) % TILE_REBUILD_PERIOD == 0) launch_tiles(h, h->stream);
+                if ((done + i) > 0 && (done + i) % COMPACT_PERIOD == 0) launch_compact(h, h->stream);
                 launch_iteration(h, h->stream, false);
             }
             done += need;
@@ -619,6 +600,16 @@ extern "C" int crim_profile(crim_t* h, double* search_ms, long* search_launches,
     if (search_ms) *search_ms = h->prof_ms;
     if (search_launches) *search_launches = h->prof_launches;
     if (evals) *evals = h->prof_evals;
+    return CRIM_OK;
+}
+
+// Diagnostic: copies the 64 stamp slots (see STAMP in crim_kernels.h); zeros unless the library
+// was built with -DCRIM_STAMPS.  Not part of the public header.
+extern "C" int crim_debug_stamps(crim_t* h, long long* out64) {
+    if (!h || !out64) return fail(CRIM_ERR_ARG, "crim_debug_stamps: null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(out64, h->prm.dbg, 64 * sizeof(long long), hipMemcpyDeviceToHost));
     return CRIM_OK;
 }
 

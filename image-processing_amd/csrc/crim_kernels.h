@@ -9,6 +9,18 @@
 
 #include "crim_types.h"
 
+// Diagnostic build only (-DCRIM_STAMPS): thread 0 of block 0 records the 100 MHz wall clock at
+// named points of each iteration kernel into a buffer nothing else reads.
+#ifdef CRIM_STAMPS
+#define STAMP(slot)                                                                         \
+    do {                                                                                    \
+        if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)      \
+            p.dbg[slot] = wall_clock64();                                                   \
+    } while (0)
+#else
+#define STAMP(slot) do {} while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------
@@ -108,26 +120,40 @@ struct FrontEval {
     double cnew, data, prio;
 };
 
-#define PG 8   // lanes that cooperate on one front pixel
+#ifndef PG
+#define PG 4   // lanes that cooperate on one front pixel (1, 2, 4 or 8)
+#endif
 
-// NumPy pairwise leaf (n <= 128) computed by PG = 8 cooperating lanes: lane j owns NumPy's
-// accumulator j; the accumulators are combined in NumPy's order by an xor butterfly (floating
-// point addition is commutative, so both partners of an exchange get identical bits).  Every
-// lane returns the full sum.
+// NumPy pairwise leaf (n <= 128) computed by PG cooperating lanes.  NumPy keeps eight
+// accumulators r[0..7] (r[j] sums elements j, j+8, ...) and combines them as
+// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)).  Lane l owns the 8/PG adjacent accumulators
+// r[l*8/PG ...], reduces them in that tree order, and the lanes finish the tree with an xor
+// butterfly (floating-point addition is commutative, so both partners of an exchange obtain
+// identical bits).  Every lane returns the full sum.
 __device__ __forceinline__ double pw_leaf8(const PatchReader& a, int lo, int n, int l) {
     if (n < 8) {
         double r = -0.0;
         for (int i = 0; i < n; ++i) r += a(lo + i);
         return r;
     }
+    constexpr int A = 8 / PG;
     const int lim = n - (n % 8);
-    double r = a(lo + l);
-    for (int i = 8; i < lim; i += 8) r += a(lo + i + l);
-    r = r + __shfl_xor(r, 1, PG);
-    r = r + __shfl_xor(r, 2, PG);
-    r = r + __shfl_xor(r, 4, PG);
-    for (int i = lim; i < n; ++i) r += a(lo + i);
-    return r;
+    double r[A];
+#pragma unroll
+    for (int k = 0; k < A; ++k) r[k] = a(lo + l * A + k);
+    for (int i = 8; i < lim; i += 8) {
+#pragma unroll
+        for (int k = 0; k < A; ++k) r[k] += a(lo + i + l * A + k);
+    }
+    double t;
+    if (A == 8) t = ((r[0] + r[1 % A]) + (r[2 % A] + r[3 % A])) + ((r[4 % A] + r[5 % A]) + (r[6 % A] + r[7 % A]));
+    else if (A == 4) t = (r[0] + r[1 % A]) + (r[2 % A] + r[3 % A]);
+    else if (A == 2) t = r[0] + r[1 % A];
+    else t = r[0];
+#pragma unroll
+    for (int off = 1; off < PG; off <<= 1) t = t + __shfl_xor(t, off, PG);
+    for (int i = lim; i < n; ++i) t += a(lo + i);
+    return t;
 }
 template <int D>
 __device__ __forceinline__ double pw_sum8(const PatchReader& a, int lo, int n, int l) {
@@ -172,7 +198,7 @@ __device__ __forceinline__ FrontEval eval_front_pixel(const Params& p, const int
 
     // first maximum of the gradient magnitude inside the patch (:183-211).  grad holds
     // (2*gy, 2*gx) as integers; comparing 4*|g|^2 orders exactly like comparing sqrt(|g|^2).
-    // Lane l scans elements l, l+8, ... of the flattened patch; the group keeps the largest
+    // Lane l scans elements l, l+PG, ... of the flattened patch; the group keeps the largest
     // magnitude and, among equals, the smallest flattened index.
     int best = -1, beste = 0x7fffffff, bpk = 0;
     for (int e = l; e < n; e += PG) {
@@ -246,8 +272,8 @@ __device__ __forceinline__ void lab_planes(const Params& p, int B_, int G_, int 
 // ------------------------------------------------------------------------------------------
 
 // One block per 16x16 tile: normalises the mask to {0,1}, derives confidence, grey and the
-// search planes, counts masked pixels per tile and grows the image's mask bounding box.
-__global__ __launch_bounds__(256) void k_init_pixels(Params p, int first, int* bbox) {
+// search planes and counts the masked pixels.
+__global__ __launch_bounds__(256) void k_init_pixels(Params p, int first) {
     const int b = first + blockIdx.z;
     const int y = blockIdx.y * CRIM_TILE + (threadIdx.x >> 4);
     const int x = blockIdx.x * CRIM_TILE + (threadIdx.x & 15);
@@ -268,17 +294,9 @@ __global__ __launch_bounds__(256) void k_init_pixels(Params p, int first, int* b
         lab_planes(p, B_, G_, R_, pl);
         uint8_t* base = p.planes + (size_t)b * 5 * p.H * p.Wp + (size_t)y * p.Wp + x;
         for (int k = 0; k < 5; ++k) base[(size_t)k * p.H * p.Wp] = pl[k];
-        if (m) {
-            int* bb = bbox + 4 * b;
-            atomicMin(&bb[0], y); atomicMax(&bb[1], y);
-            atomicMin(&bb[2], x); atomicMax(&bb[3], x);
-        }
     }
     const int cnt = __syncthreads_count(m);
-    if (threadIdx.x == 0) {
-        p.tilecnt[((size_t)b * p.tny + blockIdx.y) * p.tnx + blockIdx.x] = cnt;
-        if (cnt) atomicAdd(&p.st[b].remaining, cnt);
-    }
+    if (threadIdx.x == 0 && cnt) atomicAdd(&p.st[b].remaining, cnt);
 }
 
 // Gradient field and window-validity map; needs the normalised mask of the whole image.
@@ -298,18 +316,21 @@ __global__ __launch_bounds__(256) void k_init_fields(Params p, int first) {
                 if (mk[(size_t)(y + i) * p.W + x + j]) { inv = 1; break; }
     }
     p.invalid[((size_t)b * p.H + y) * p.Wi + x] = (uint8_t)inv;
+    int nb[9];
+    if (front_weight(mk, p.H, p.W, y, x, nb) > 0) {
+        const unsigned k = atomicAdd(&p.st[b].fcount, 1u);
+        p.flist[(size_t)b * 2 * p.fcap + k] = y * p.W + x;
+    }
 }
 
-__global__ void k_init_state(Params p, int first, int count, int* bbox) {
+__global__ void k_init_state(Params p, int first, int count) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     ImgState* s = p.st + first + i;
-    s->iter = 0; s->live = 1; s->cur = 0; s->remaining = 0; s->has_fix = 0;
-    s->fix_r0 = s->fix_r1 = s->fix_c0 = s->fix_c1 = 0;
+    s->iter = 0; s->live = 1; s->cur = 0; s->remaining = 0;
+    s->fcount = 0; s->fsel = 0;
     s->pcount = 0; s->scount = 0; s->stalled = 0; s->bound = 0x7fffffff;
     p.desc[first + i].live = 0;
-    int* bb = bbox + 4 * (first + i);
-    bb[0] = 0x7fffffff; bb[1] = -1; bb[2] = 0x7fffffff; bb[3] = -1;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -320,106 +341,75 @@ __device__ __forceinline__ bool better_prio(double pa, int ia, double pb, int ib
     return pa > pb || (pa == pb && ia < ib);
 }
 
-// Is tile (tX, tY) worth scanning: masked pixels in its 3x3 tile neighbourhood (a front pixel is
-// a known pixel with a masked diagonal neighbour), or overlap with the previous patch box grown
-// by one pixel (confidence buffer fix-up, see k_priority).
-__device__ __forceinline__ bool tile_active(const Params& p, const int* tcnt, const ImgState* st,
-                                            int tX, int tY, bool* fix_out) {
-    int nbsum = 0;
-    for (int dy = -1; dy <= 1; ++dy)
-        for (int dx = -1; dx <= 1; ++dx) {
-            const int yy = tY + dy, xx = tX + dx;
-            if (yy >= 0 && yy < p.tny && xx >= 0 && xx < p.tnx) nbsum += tcnt[yy * p.tnx + xx];
-        }
-    const int fr0 = st->fix_r0 - 1, fr1 = st->fix_r1 + 1, fc0 = st->fix_c0 - 1, fc1 = st->fix_c1 + 1;
-    const bool fix = st->has_fix && tY * CRIM_TILE <= fr1 && tY * CRIM_TILE + CRIM_TILE - 1 >= fr0 &&
-                     tX * CRIM_TILE <= fc1 && tX * CRIM_TILE + CRIM_TILE - 1 >= fc0;
-    *fix_out = fix;
-    return nbsum != 0 || fix;
-}
+// The fill front is kept as a per-image list of pixel positions.  A known pixel joins the front
+// when a diagonal neighbour is masked and leaves it when the last such neighbour is filled; the
+// mask only shrinks, so a pixel enters the list at most once (at upload, or when it is filled
+// next to still-masked pixels) and stale entries are simply skipped until the next compaction.
 
-// Rebuilds the per-image list of tiles the priority scan must visit.  The mask only shrinks, so
-// a list stays a valid superset until the next rebuild; the scan re-checks every tile anyway.
-__global__ __launch_bounds__(256) void k_tiles(Params p) {
+// Drops the entries that are no longer on the front (one block per image).
+__global__ __launch_bounds__(1024) void k_compact(Params p) {
     const int b = blockIdx.x;
-    const ImgState* st = p.st + b;
+    ImgState* st = p.st + b;
     if (!st->live) return;
-    __shared__ int s_n;
+    __shared__ unsigned s_n;
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
-    const int* tcnt = p.tilecnt + (size_t)b * p.tny * p.tnx;
-    int* tl = p.tlist + (size_t)b * p.tnx * p.tny;
-    for (int i = threadIdx.x; i < p.ptnx * p.ptny; i += 256) {
-        const int tX = p.ptx0 + i % p.ptnx, tY = p.pty0 + i / p.ptnx;
-        bool fix;
-        if (tile_active(p, tcnt, st, tX, tY, &fix)) tl[atomicAdd(&s_n, 1)] = tY * p.tnx + tX;
+    const size_t HW = (size_t)p.H * p.W;
+    const uint8_t* mask = p.mask + b * HW;
+    const int sel = st->fsel;
+    const int* src = p.flist + ((size_t)b * 2 + sel) * p.fcap;
+    int* dst = p.flist + ((size_t)b * 2 + (sel ^ 1)) * p.fcap;
+    const unsigned n = st->fcount;
+    for (unsigned e = threadIdx.x; e < n; e += 1024) {
+        const int pos = src[e];
+        const int y = pos / p.W, x = pos - y * p.W;
+        int nb[9];
+        if (front_weight(mask, p.H, p.W, y, x, nb) > 0) dst[atomicAdd(&s_n, 1u)] = pos;
     }
     __syncthreads();
-    if (threadIdx.x == 0) p.ntiles[b] = s_n;
+    if (threadIdx.x == 0) { st->fcount = s_n; st->fsel = sel ^ 1; }
 }
 
-// grid (pgrid, B): block g of image b walks tiles g, g + pgrid, ... of that image's tile list.
+// grid (pgrid, B): groups of PG lanes walk the image's front list; every live entry gets its new
+// confidence (written to the other confidence buffer: the update is Jacobi-style, :115-127) and
+// its priority; each block emits its best (priority, position).
 __global__ __launch_bounds__(256) void k_priority(Params p) {
     const int b = blockIdx.y;
     ImgState* st = p.st + b;
+    STAMP(0);
     if (!st->live) return;
     const int H = p.H, W = p.W;
     const size_t HW = (size_t)H * W;
-    const int ntiles = p.ntiles[b];
-    if ((int)blockIdx.x >= ntiles) return;
-    const int* tl = p.tlist + (size_t)b * p.tnx * p.tny;
-    const int* tcnt = p.tilecnt + (size_t)b * p.tny * p.tnx;
+    const int n = (int)st->fcount;
+    STAMP(1);
+    constexpr int GPB = 256 / PG;
+    if ((int)blockIdx.x * GPB >= n) return;
+    const int* fl = p.flist + ((size_t)b * 2 + st->fsel) * p.fcap;
     const int cur = st->cur;
     const double* ccur = p.conf + ((size_t)b * 2 + cur) * HW;
     double* cnxt = p.conf + ((size_t)b * 2 + (cur ^ 1)) * HW;
     const uint8_t* mask = p.mask + b * HW;
     const int* grad = p.grad + b * HW;
-    // Pixels written to the current confidence buffer by the previous iteration (its front and
-    // its filled patch) that are not rewritten now must be carried over to the other buffer;
-    // all of them lie within one pixel of the previous patch box.
-    const int fr0 = st->fix_r0 - 1, fr1 = st->fix_r1 + 1, fc0 = st->fix_c0 - 1, fc1 = st->fix_c1 + 1;
 
-    __shared__ int s_n;
-    __shared__ int s_list[256];
     __shared__ double s_bp[4];
     __shared__ int s_bi[4];
     const int tid = threadIdx.x;
     const int grp = tid / PG, l = tid % PG;
     double bestP = -1.0;
     int bestI = 0x7fffffff;
-
-    for (int ti = blockIdx.x; ti < ntiles; ti += gridDim.x) {
-        const int tile = tl[ti];
-        const int tY = tile / p.tnx, tX = tile - tY * p.tnx;
-        bool fix_tile;
-        if (!tile_active(p, tcnt, st, tX, tY, &fix_tile)) continue;   // block-uniform
-        if (tid == 0) s_n = 0;
-        __syncthreads();
-        const int y = tY * CRIM_TILE + (tid >> 4), x = tX * CRIM_TILE + (tid & 15);
-        int nb[9];
-        int F = 0;
-        if (y < H && x < W) {
-            F = front_weight(mask, H, W, y, x, nb);
-            if (F == 0 && fix_tile && y >= fr0 && y <= fr1 && x >= fc0 && x <= fc1)
-                cnxt[(size_t)y * W + x] = ccur[(size_t)y * W + x];
+    for (int e = blockIdx.x * GPB + grp; e < n; e += gridDim.x * GPB) {
+        const int pos = fl[e];
+        const int fy = pos / W, fx = pos - fy * W;
+        int fnb[9];
+        const int fF = front_weight(mask, H, W, fy, fx, fnb);
+        if (fF == 0) continue;   // left the front since the last compaction
+        const FrontEval ev = eval_front_pixel(p, grad, ccur, fy, fx, fF, fnb, l);
+        if (l == 0) {
+            cnxt[pos] = ev.cnew;
+            if (better_prio(ev.prio, pos, bestP, bestI)) { bestP = ev.prio; bestI = pos; }
         }
-        if (F > 0) s_list[atomicAdd(&s_n, 1)] = tid;
-        __syncthreads();
-        const int n = s_n;
-        for (int e = grp; e < n; e += 256 / PG) {
-            const int t = s_list[e];
-            const int fy = tY * CRIM_TILE + (t >> 4), fx = tX * CRIM_TILE + (t & 15);
-            int fnb[9];
-            const int fF = front_weight(mask, H, W, fy, fx, fnb);
-            const FrontEval ev = eval_front_pixel(p, grad, ccur, fy, fx, fF, fnb, l);
-            if (l == 0) {
-                cnxt[(size_t)fy * W + fx] = ev.cnew;
-                const int pos = fy * W + fx;
-                if (better_prio(ev.prio, pos, bestP, bestI)) { bestP = ev.prio; bestI = pos; }
-            }
-        }
-        __syncthreads();   // s_n / s_list are reused by the next tile
     }
+    STAMP(2);
     // block arg-max: highest priority, lowest row-major index on ties (np.argmax, :217)
     for (int off = 32; off > 0; off >>= 1) {
         const double op = __shfl_down(bestP, off);
@@ -438,6 +428,7 @@ __global__ __launch_bounds__(256) void k_priority(Params p) {
             p.plist[(size_t)b * p.pgrid + k] = e;
         }
     }
+    STAMP(3);
 }
 
 // Full-frame front / data / priority of the iteration that would run next (debug / parity
@@ -481,6 +472,7 @@ __global__ __launch_bounds__(256) void k_select(Params p) {
         if (tid == 0) d->live = 0;
         return;
     }
+    STAMP(8);
     const int H = p.H, W = p.W, P = p.P, ND = p.ND;
     const size_t HW = (size_t)H * W;
     __shared__ double s_bp[4];
@@ -489,6 +481,7 @@ __global__ __launch_bounds__(256) void k_select(Params p) {
     __shared__ uint8_t s_k[CRIM_PMAX * CRIM_PMAX];
     __shared__ int8_t s_t[3][CRIM_PMAX * CRIM_PMAX];
     __shared__ int s_soff;
+    __shared__ int s_rowmask;
 
     const unsigned n = st->pcount;
     const PEntry* pl = p.plist + (size_t)b * p.pgrid;
@@ -504,7 +497,7 @@ __global__ __launch_bounds__(256) void k_select(Params p) {
         if (better_prio(op, oi, bestP, bestI)) { bestP = op; bestI = oi; }
     }
     if ((tid & 63) == 0) { s_bp[tid >> 6] = bestP; s_bi[tid >> 6] = bestI; }
-    if (tid == 0) s_soff = 0;
+    if (tid == 0) { s_soff = 0; s_rowmask = 0; }
     __syncthreads();
     if (tid == 0) {
         for (int w = 1; w < 4; ++w)
@@ -513,6 +506,7 @@ __global__ __launch_bounds__(256) void k_select(Params p) {
         s_target = (bestP > 0.0) ? bestI : 0;
     }
     __syncthreads();
+    STAMP(9);
     const int pos = s_target;
     const int tr = pos / W, tc = pos - tr * W;
     const int r0 = imax(0, tr - p.half), r1 = imin(tr + p.half, H - 1);
@@ -535,6 +529,7 @@ __global__ __launch_bounds__(256) void k_select(Params p) {
                 t2 = (int8_t)planes[(size_t)2 * H * p.Wp + o];
                 // sum k*T~^2 - sum k*T^2 with T = T~ + 128
                 soff_local += -256 * (t0 + t1 + t2) - 3 * 16384;
+                atomicOr(&s_rowmask, 1 << i);
             }
         }
         s_k[e] = (uint8_t)k;
@@ -544,6 +539,7 @@ __global__ __launch_bounds__(256) void k_select(Params p) {
     }
     if (soff_local) atomicAdd(&s_soff, soff_local);
     __syncthreads();
+    STAMP(10);
 
     // shifted template rows: dword j of shift s covers template columns 4j-s .. 4j-s+3
     const int total = 5 * P * 4 * ND;
@@ -567,12 +563,7 @@ __global__ __launch_bounds__(256) void k_select(Params p) {
         d->tmpl[e] = v;
     }
     if (tid == 0) {
-        int rowmask = 0;
-        for (int i = 0; i < P; ++i) {
-            int any = 0;
-            for (int j = 0; j < P; ++j) any |= s_k[i * P + j];
-            if (any) rowmask |= 1 << i;
-        }
+        const int rowmask = s_rowmask;
         d->live = 1;
         d->tr = tr; d->tc = tc; d->r0 = r0; d->c0 = c0; d->ph = ph; d->pw = pw;
         d->clipped = (ph != P || pw != P) ? 1 : 0;
@@ -586,6 +577,7 @@ __global__ __launch_bounds__(256) void k_select(Params p) {
         st->scount = 0;
         st->bound = 0x7fffffff;
     }
+    STAMP(11);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -866,10 +858,11 @@ __global__ __launch_bounds__(256) void k_update(Params p) {
     if (!st->live) return;
     const Desc* __restrict__ d = p.desc + b;
     const int tid = threadIdx.x;
+    STAMP(16);
     const int H = p.H, W = p.W, P = p.P;
     const size_t HW = (size_t)H * W;
     constexpr int PM = CRIM_PMAX;
-    constexpr int MR = 3 * PM - 2;    // mask region edge for the validity update
+    constexpr int MR = 3 * PM - 2 + 2;  // mask region edge: patch grown by max(P-1, 2) per side
     constexpr int GR = PM + 4;        // grey region edge for the gradient update
     __shared__ double s_c[4];
     __shared__ unsigned s_i[4];
@@ -879,6 +872,9 @@ __global__ __launch_bounds__(256) void k_update(Params p) {
     __shared__ uint8_t s_px[PM * PM][9];   // source pixel: B,G,R, 5 planes, grey
     __shared__ uint8_t s_m[MR * MR];
     __shared__ uint8_t s_g[GR * GR];
+    __shared__ unsigned s_fill[(PM * PM + 31) / 32];   // bit e: patch element e was filled
+    __shared__ unsigned long long s_rb[MR][2];         // per snapshot row: bit j = pixel j masked
+    __shared__ unsigned long long s_rw[MR][2];         // OR of P consecutive rows
 
     // ---- arg-min over the per-block candidates: lowest cost, lowest row-major index (:264)
     const unsigned n = st->scount;
@@ -896,6 +892,7 @@ __global__ __launch_bounds__(256) void k_update(Params p) {
     }
     if ((tid & 63) == 0) { s_c[tid >> 6] = bc; s_i[tid >> 6] = bi; }
     if (tid == 0) s_filled = 0;
+    if (tid < (PM * PM + 31) / 32) s_fill[tid] = 0;
     __syncthreads();
     if (tid == 0) {
         for (int w = 1; w < 4; ++w)
@@ -905,16 +902,18 @@ __global__ __launch_bounds__(256) void k_update(Params p) {
         s_cost = bc;
     }
     __syncthreads();
+    STAMP(17);
     const int ncx = d->ncx;
     const int sy = (int)(s_src / (unsigned)ncx), sx = (int)(s_src % (unsigned)ncx);
     const int r0 = d->r0, c0 = d->c0, ph = d->ph, pw = d->pw;
-    const int r1 = r0 + ph - 1, c1 = c0 + pw - 1;
     uint8_t* mask = p.mask + b * HW;
     uint8_t* bgr = p.bgr + b * HW * 3;
     uint8_t* grey = p.grey + b * HW;
     uint8_t* planes = p.planes + (size_t)b * 5 * H * p.Wp;
     const size_t PS = (size_t)H * p.Wp;
-    double* cnxt = p.conf + ((size_t)b * 2 + (st->cur ^ 1)) * HW;
+    // loop state is read once, up front: thread 0 rewrites it at the end of this kernel
+    const int cur = st->cur, fsel = st->fsel;
+    double* cnxt = p.conf + ((size_t)b * 2 + (cur ^ 1)) * HW;
 
     // ---- snapshot: source pixels, the mask around the patch, the grey values around it
     for (int e = tid; e < ph * pw; e += 256) {
@@ -925,8 +924,9 @@ __global__ __launch_bounds__(256) void k_update(Params p) {
         for (int k = 0; k < 5; ++k) s_px[e][3 + k] = planes[k * PS + so];
         s_px[e][8] = grey[s];
     }
-    const int mr0 = r0 - (P - 1), mc0 = c0 - (P - 1);
-    const int mrh = ph + 2 * (P - 1), mrw = pw + 2 * (P - 1);
+    const int mg = P - 1 > 2 ? P - 1 : 2;   // margin of the mask snapshot around the patch
+    const int mr0 = r0 - mg, mc0 = c0 - mg;
+    const int mrh = ph + 2 * mg, mrw = pw + 2 * mg;
     for (int e = tid; e < mrh * mrw; e += 256) {
         const int i = e / mrw, j = e - i * mrw;
         const int yy = mr0 + i, xx = mc0 + j;
@@ -946,10 +946,10 @@ __global__ __launch_bounds__(256) void k_update(Params p) {
         s_g[i * GR + j] = v;
     }
     __syncthreads();
+    STAMP(18);
 
     // ---- fill the masked pixels of the target patch (:274-308)
     const double cnew = d->cnew;
-    int* tcnt = p.tilecnt + (size_t)b * p.tny * p.tnx;
     int filled = 0;
     for (int e = tid; e < ph * pw; e += 256) {
         const int i = e / pw, j = e - i * pw;
@@ -962,28 +962,88 @@ __global__ __launch_bounds__(256) void k_update(Params p) {
             grey[q] = s_px[e][8];
             cnxt[q] = cnew;
             mask[q] = 0;
-            s_m[(i + P - 1) * MR + (j + P - 1)] = 0;
+            s_m[(i + mg) * MR + (j + mg)] = 0;
             s_g[(i + 2) * GR + (j + 2)] = s_px[e][8];
-            atomicSub(&tcnt[(yy / CRIM_TILE) * p.tnx + xx / CRIM_TILE], 1);
+            atomicOr(&s_fill[e >> 5], 1u << (e & 31));
             ++filled;
         }
     }
     if (filled) atomicAdd(&s_filled, filled);
     __syncthreads();
+    STAMP(19);
 
     // ---- window-validity map: origins whose P x P window touches the patch
     uint8_t* inv = p.invalid + (size_t)b * H * p.Wi;
     const int oh = ph + P - 1, ow = pw + P - 1;   // origins r0-P+1 .. r1, c0-P+1 .. c1
+    // Row bitmasks of the snapshot by wave ballots, then the OR over P consecutive rows, then one
+    // shifted test per origin.
+    const int og = mg - (P - 1);   // offset of the first origin inside the snapshot
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int row = wave; row < mrh; row += 4) {
+            const unsigned long long lo = __ballot(lane < mrw && s_m[row * MR + lane]);
+            const unsigned long long hi = __ballot(64 + lane < mrw && s_m[row * MR + 64 + lane]);
+            if (lane == 0) { s_rb[row][0] = lo; s_rb[row][1] = hi; }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < oh; i += 256) {
+        unsigned long long lo = 0, hi = 0;
+        for (int a = 0; a < P; ++a) { lo |= s_rb[og + i + a][0]; hi |= s_rb[og + i + a][1]; }
+        s_rw[i][0] = lo; s_rw[i][1] = hi;
+    }
+    __syncthreads();
     for (int e = tid; e < oh * ow; e += 256) {
         const int i = e / ow, j = e - i * ow;
-        const int oy = mr0 + i, ox = mc0 + j;
+        const int oy = r0 - (P - 1) + i, ox = c0 - (P - 1) + j;
         if (oy < 0 || ox < 0 || oy > H - P || ox > W - P) continue;
-        int any = 0;
-        for (int a = 0; a < P && !any; ++a)
-            for (int c = 0; c < P; ++c)
-                if (s_m[(i + a) * MR + j + c]) { any = 1; break; }
-        inv[(size_t)oy * p.Wi + ox] = (uint8_t)any;
+        // bits [og + j, og + j + P) of the 128-bit row window
+        const int sft = og + j;
+        const unsigned long long lo = s_rw[i][0], hi = s_rw[i][1];
+        unsigned long long w;
+        if (sft == 0) w = lo;
+        else if (sft < 64) w = (lo >> sft) | (hi << (64 - sft));
+        else w = hi >> (sft - 64);
+        const unsigned long long pm = (1ull << P) - 1ull;
+        inv[(size_t)oy * p.Wi + ox] = (uint8_t)((w & pm) != 0);
     }
+    // ---- fill front: a filled pixel with a still-masked diagonal neighbour joins the list
+    {
+        auto M = [&](int y2, int x2) -> int {
+            return (int)s_m[(reflect101(y2, H) - mr0) * MR + (reflect101(x2, W) - mc0)];
+        };
+        int* fl = p.flist + ((size_t)b * 2 + fsel) * p.fcap;
+        for (int e = tid; e < ph * pw; e += 256) {
+            if (!(s_fill[e >> 5] & (1u << (e & 31)))) continue;
+            const int i = e / pw, j = e - i * pw;
+            const int yy = r0 + i, xx = c0 + j;
+            if (M(yy - 1, xx - 1) + M(yy - 1, xx + 1) + M(yy + 1, xx - 1) + M(yy + 1, xx + 1) > 0)
+                fl[atomicAdd(&st->fcount, 1u)] = yy * W + xx;
+        }
+    }
+    // ---- confidence buffers: the buffer that was current during this iteration is stale on this
+    // iteration's front and patch.  Front pixels that stay on the front are rewritten by the next
+    // iteration; every other stale pixel lies within one pixel of the patch box and is refreshed
+    // here (pixels that remain on the front are refreshed too, harmlessly).
+    {
+        double* cold = p.conf + ((size_t)b * 2 + cur) * HW;
+        const int ch = ph + 2, cw = pw + 2;
+        for (int e = tid; e < ch * cw; e += 256) {
+            const int i = e / cw, j = e - i * cw;
+            const int yy = r0 - 1 + i, xx = c0 - 1 + j;
+            if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+            const size_t q = (size_t)yy * W + xx;
+            double v;
+            const int pi = i - 1, pj = j - 1;
+            if (pi >= 0 && pi < ph && pj >= 0 && pj < pw &&
+                (s_fill[(pi * pw + pj) >> 5] & (1u << ((pi * pw + pj) & 31))))
+                v = cnew;
+            else
+                v = cnxt[q];
+            cold[q] = v;
+        }
+    }
+    STAMP(21);
     // ---- gradient field: pixels within one pixel of the patch
     int* grad = p.grad + b * HW;
     const int uh = ph + 2, uw = pw + 2;
@@ -1003,6 +1063,7 @@ __global__ __launch_bounds__(256) void k_update(Params p) {
         else gx2 = G(yy, xx + 1) - G(yy, xx - 1);
         grad[(size_t)yy * W + xx] = (gy2 & 0xffff) | (int)((unsigned)gx2 << 16);
     }
+    STAMP(22);
     // ---- loop state and trace
     if (tid == 0) {
         const int nf = s_filled;
@@ -1016,10 +1077,9 @@ __global__ __launch_bounds__(256) void k_update(Params p) {
         }
         st->remaining = rem;
         st->iter = it + 1;
-        st->cur ^= 1;
-        st->has_fix = 1;
-        st->fix_r0 = r0; st->fix_r1 = r1; st->fix_c0 = c0; st->fix_c1 = c1;
+        st->cur = cur ^ 1;
         if (rem <= 0) st->live = 0;
         else if (nf == 0) { st->live = 0; st->stalled = 1; }
     }
+    STAMP(23);
 }

@@ -21,13 +21,13 @@ struct ImgState {
     int live;        // 1 while the next iteration must run
     int cur;         // which of the two confidence buffers is current
     int remaining;   // masked pixels left
-    int has_fix;     // a previous iteration exists: its patch box needs the buffer fix-up
-    int fix_r0, fix_r1, fix_c0, fix_c1;
+    unsigned fcount; // entries in the current front list
+    int fsel;        // which of the two front-list buffers is current
     unsigned pcount; // entries in this image's priority partial list
     unsigned scount; // entries in this image's search partial list
     int stalled;     // an iteration filled nothing while pixels remained
     int bound;       // running upper bound on floor(best cost) for search pruning
-    int pad[3];
+    int pad[6];
 };
 
 // Best front pixel of one priority tile.
@@ -72,8 +72,7 @@ struct Params {
     int ND;       // dwords per shifted template row
     int Wp;       // pitch of the search byte planes
     int Wi;       // pitch of the window-validity map
-    int tnx, tny; // priority tile grid over the whole image
-    int ptx0, pty0, ptnx, ptny;  // tile window the priority scan covers
+    int tnx, tny; // 16x16 tile grid over the whole image (upload-time kernels)
     int snx, sny; // search block grid
     int pgrid;    // priority-scan blocks per image
     int generic;  // use the unspecialised search kernel
@@ -85,14 +84,14 @@ struct Params {
     int* grad;         // [B][H][W] packed (int16 2*gy, int16 2*gx)
     double* conf;      // [B][2][H][W]
     uint8_t* invalid;  // [B][H][Wi] 1: the P x P window at this origin holds a masked pixel
-    int* tilecnt;      // [B][tny][tnx] masked pixels per tile
     ImgState* st;
     Desc* desc;
-    int* tlist;        // [B][tnx*tny] tiles the priority scan visits
-    int* ntiles;       // [B]
+    long fcap;         // capacity of one front-list buffer (H*W)
+    int* flist;        // [B][2][fcap] pixel positions on (or recently on) the fill front
     PEntry* plist;     // [B][pgrid]
     SEntry* slist;     // [B][snx*sny]
     crim_iter_rec* trace;  // [B][trace_cap]
+    long long* dbg;        // diagnostic stamps (only written by -DCRIM_STAMPS builds)
     const uint16_t* gamma_tab;
     const uint16_t* cbrt_tab;
     int coef[9];

@@ -1,0 +1,30 @@
+"""Diagnostic: per-phase wall-clock stamps of the iteration kernels (needs the -DCRIM_STAMPS
+build in image-processing_amd/lib_dbg)."""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "image-processing_amd"))
+import numpy as np
+import crim_hip_capi as capi
+capi.LIB_PATH = os.path.join(ROOT, "image-processing_amd", "lib_dbg", "libcriminisi_hip.so")
+import crim_synth
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+H = W = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+imgs = np.stack([crim_synth.xray_like(H, W, 2000 + i) for i in range(min(B, 8))])
+masks = np.stack([crim_synth.blob_mask(H, W, 2000 + i, 0.10, 9) for i in range(min(B, 8))])
+imgs = np.concatenate([imgs] * (B // len(imgs) + 1))[:B]; masks = np.concatenate([masks] * (B // len(masks) + 1))[:B]
+lib = capi.load_library()
+lib.crim_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+eng = capi.Engine(H, W, 9, batch=B, flags=capi.FLAG_EAGER)
+eng.upload(imgs, masks)
+eng.run(max_iters=40)
+acc = {}
+for it in range(20):
+    eng.run(max_iters=1)
+    st = np.zeros(64, np.int64); lib.crim_debug_stamps(eng._h, st.ctypes.data)
+    for name, slots in (("priority", range(0, 4)), ("select", range(8, 12)), ("update", range(16, 24))):
+        v = st[list(slots)]
+        d = np.diff(v) * 10  # ns (100 MHz)
+        acc.setdefault(name, []).append(d)
+    acc.setdefault("gaps", []).append(np.array([st[8] - st[3], st[16] - st[11]]) * 10)
+for k, v in acc.items():
+    print(k, "mean ns per phase:", np.mean(v, axis=0).astype(int).tolist(), "total", int(np.mean(np.sum(v, axis=1))))
