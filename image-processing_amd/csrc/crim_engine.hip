@@ -184,17 +184,22 @@ static void launch_search(crim_engine* h, hipStream_t s) {
 static bool has_fast_search(int P) { return P >= 3 && P <= 15 && (P & 1); }
 
 // One iteration of criminisi_inpainter.py:51-83 as four dependent launches.
-// Front-list compaction: stale entries only cost a skipped lookup, so it runs rarely.
+// Tile-list rebuild: stale entries only cost a skipped lookup, so it runs rarely.
 static void launch_compact(crim_engine* h, hipStream_t s) {
     const Params& p = h->prm;
-    hipLaunchKernelGGL(k_compact, dim3(p.B), dim3(1024), 0, s, p);
+    hipLaunchKernelGGL(k_tiles, dim3(p.B), dim3(256), 0, s, p);
+}
+
+static size_t priority_lds_bytes(const Params& p) {
+    const size_t rs = CRIM_TILE + 2 * p.half;
+    return rs * rs * 12 + CRIM_TILE * CRIM_TILE * 4 + (CRIM_TILE + 2) * (CRIM_TILE + 2) + 16;
 }
 
 #define COMPACT_PERIOD 16
 
 static void launch_iteration(crim_engine* h, hipStream_t s, bool profile) {
     const Params& p = h->prm;
-    hipLaunchKernelGGL(k_priority, dim3(p.pgrid, p.B), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(k_priority, dim3(p.pgrid, p.B), dim3(64), priority_lds_bytes(p), s, p);
     hipLaunchKernelGGL(k_select, dim3(p.B), dim3(256), 0, s, p);
     if (profile) (void)hipEventRecord(h->ev[2 * h->ev_used], s);
     launch_search(h, s);
@@ -242,7 +247,7 @@ extern "C" void crim_destroy(crim_t* h) {
     free_graphs(h);
     for (auto e : h->ev) (void)hipEventDestroy(e);
     Params& p = h->prm;
-    void* bufs[] = {p.bgr, p.planes, p.mask, p.grey, p.grad, p.conf, p.invalid, p.flist, p.st,
+    void* bufs[] = {p.bgr, p.planes, p.mask, p.grey, p.grad, p.conf, p.invalid, p.tfront, p.tlist, p.st,
                     p.desc, p.plist, p.slist, p.trace, p.dbg, h->d_gamma, h->d_cbrt, h->d_peek};
     for (void* q : bufs)
         if (q) (void)hipFree(q);
@@ -299,11 +304,12 @@ extern "C" int crim_create_batch(int batch, int H, int W, int patch_size, int de
     alloc((void**)&p.grad, Bz * HW * sizeof(int));
     alloc((void**)&p.conf, Bz * 2 * HW * sizeof(double));
     alloc((void**)&p.invalid, Bz * H * p.Wi);
-    p.fcap = (long)HW;
-    alloc((void**)&p.flist, Bz * 2 * HW * sizeof(int));
+    p.tcap = 2 * p.tnx * p.tny;
+    alloc((void**)&p.tfront, Bz * p.tnx * p.tny * sizeof(int));
+    alloc((void**)&p.tlist, Bz * p.tcap * sizeof(int));
     alloc((void**)&p.st, Bz * sizeof(ImgState));
     alloc((void**)&p.desc, Bz * sizeof(Desc));
-    p.pgrid = std::min(1024, std::max(8, 4096 / batch));
+    p.pgrid = std::min(std::min(2048, p.tnx * p.tny), std::max(16, 16384 / batch));
     alloc((void**)&p.plist, Bz * p.pgrid * sizeof(PEntry));
     alloc((void**)&p.slist, Bz * p.snx * p.sny * sizeof(SEntry));
     alloc((void**)&p.dbg, 64 * sizeof(long long));

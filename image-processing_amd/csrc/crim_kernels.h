@@ -45,65 +45,32 @@ __device__ __forceinline__ const_u32_ptr as_const_u32(const void* p) {
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 
+// A rectangular window of a 2-D field: element (y, x) in image coordinates lives at
+// base[(y - oy) * pitch + (x - ox)].  The same code reads whole frames in global memory
+// (oy = ox = 0, pitch = W) and tiles staged in LDS.
+template <typename T>
+struct View {
+    const T* base;
+    int pitch, oy, ox;
+    __device__ __forceinline__ T at(int y, int x) const { return base[(y - oy) * pitch + (x - ox)]; }
+};
+
 // Reads element e of a row-major ph x pw window of the confidence map (flattened order).
 struct PatchReader {
-    const double* c;
-    int W, r0, c0, pw;
+    View<double> c;
+    int r0, c0, pw;
     unsigned inv;  // ceil(65536 / pw): exact floor(e / pw) for e < 2048, pw <= 31
     __device__ __forceinline__ double operator()(int e) const {
-        unsigned q = ((unsigned)e * inv) >> 16;
-        int col = e - (int)q * pw;
-        return c[(size_t)(r0 + (int)q) * W + c0 + col];
+        const unsigned q = ((unsigned)e * inv) >> 16;
+        const int col = e - (int)q * pw;
+        return c.at(r0 + (int)q, c0 + col);
     }
 };
 
-// NumPy's pairwise summation of n <= 128 doubles (np.sum in criminisi_inpainter.py:124-125
-// flattens the patch in C order): fewer than 8 elements are added sequentially, otherwise eight
-// interleaved accumulators are combined as ((0+1)+(2+3))+((4+5)+(6+7)) and the tail is added.
-__device__ __forceinline__ double pw_leaf(const PatchReader& a, int lo, int n) {
-    if (n < 8) {
-        double r = -0.0;
-        for (int i = 0; i < n; ++i) r += a(lo + i);
-        return r;
-    }
-    double r0 = a(lo), r1 = a(lo + 1), r2 = a(lo + 2), r3 = a(lo + 3);
-    double r4 = a(lo + 4), r5 = a(lo + 5), r6 = a(lo + 6), r7 = a(lo + 7);
-    int i;
-    const int lim = n - (n % 8);
-    for (i = 8; i < lim; i += 8) {
-        r0 += a(lo + i);
-        r1 += a(lo + i + 1);
-        r2 += a(lo + i + 2);
-        r3 += a(lo + i + 3);
-        r4 += a(lo + i + 4);
-        r5 += a(lo + i + 5);
-        r6 += a(lo + i + 6);
-        r7 += a(lo + i + 7);
-    }
-    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
-    for (; i < n; ++i) res += a(lo + i);
-    return res;
-}
-
-// Larger windows are halved (first half rounded down to a multiple of 8) and the halves summed,
-// as NumPy does.  Depth 3 covers n <= 1024, i.e. patch edges up to 31.
-template <int D>
-__device__ __forceinline__ double pw_sum(const PatchReader& a, int lo, int n) {
-    if (n <= 128) return pw_leaf(a, lo, n);
-    int n2 = n / 2;
-    n2 -= n2 % 8;
-    return pw_sum<D - 1>(a, lo, n2) + pw_sum<D - 1>(a, lo + n2, n - n2);
-}
-template <>
-__device__ __forceinline__ double pw_sum<0>(const PatchReader& a, int lo, int n) {
-    return pw_leaf(a, lo, n);
-}
-
-// Fill-front weight of pixel (y, x): sat_u8(Laplacian_ksize3(mask)) with the aperture
-// [[2,0,2],[0,-8,0],[2,0,2]] (criminisi_inpainter.py:103).  Also returns the 3x3 mask
-// neighbourhood in nb[] (row-major) for the normal.
-__device__ __forceinline__ int front_weight(const uint8_t* mask, int H, int W, int y, int x,
-                                            int nb[9]) {
+// 3x3 mask neighbourhood of pixel (y, x), row-major, from a whole-frame mask with
+// BORDER_REFLECT_101 (the default border of cv2.Laplacian / cv2.filter2D).
+__device__ __forceinline__ void mask_nb_global(const uint8_t* mask, int H, int W, int y, int x,
+                                               int nb[9]) {
     const int ym = reflect101(y - 1, H), yp = reflect101(y + 1, H);
     const int xm = reflect101(x - 1, W), xp = reflect101(x + 1, W);
     const uint8_t* r0 = mask + (size_t)ym * W;
@@ -112,8 +79,20 @@ __device__ __forceinline__ int front_weight(const uint8_t* mask, int H, int W, i
     nb[0] = r0[xm]; nb[1] = r0[x]; nb[2] = r0[xp];
     nb[3] = r1[xm]; nb[4] = r1[x]; nb[5] = r1[xp];
     nb[6] = r2[xm]; nb[7] = r2[x]; nb[8] = r2[xp];
-    int v = 2 * (nb[0] + nb[2] + nb[6] + nb[8]) - 8 * nb[4];
+}
+
+// Fill-front weight from the neighbourhood: sat_u8(Laplacian_ksize3(mask)) with the aperture
+// [[2,0,2],[0,-8,0],[2,0,2]] (criminisi_inpainter.py:103): positive only on a known pixel with a
+// masked diagonal neighbour.
+__device__ __forceinline__ int front_from_nb(const int nb[9]) {
+    const int v = 2 * (nb[0] + nb[2] + nb[6] + nb[8]) - 8 * nb[4];
     return v < 0 ? 0 : v;
+}
+
+__device__ __forceinline__ int front_weight(const uint8_t* mask, int H, int W, int y, int x,
+                                            int nb[9]) {
+    mask_nb_global(mask, H, W, y, x, nb);
+    return front_from_nb(nb);
 }
 
 struct FrontEval {
@@ -124,12 +103,13 @@ struct FrontEval {
 #define PG 4   // lanes that cooperate on one front pixel (1, 2, 4 or 8)
 #endif
 
-// NumPy pairwise leaf (n <= 128) computed by PG cooperating lanes.  NumPy keeps eight
-// accumulators r[0..7] (r[j] sums elements j, j+8, ...) and combines them as
-// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)).  Lane l owns the 8/PG adjacent accumulators
-// r[l*8/PG ...], reduces them in that tree order, and the lanes finish the tree with an xor
-// butterfly (floating-point addition is commutative, so both partners of an exchange obtain
-// identical bits).  Every lane returns the full sum.
+// NumPy's pairwise summation (np.sum in criminisi_inpainter.py:124-125 flattens the patch in C
+// order) of n <= 128 doubles, computed by PG cooperating lanes.  Fewer than 8 elements are added
+// sequentially.  Otherwise NumPy keeps eight accumulators r[0..7] (r[j] sums elements j, j+8,
+// ...), combines them as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) and adds the n%8 tail.  Lane l owns
+// the 8/PG adjacent accumulators r[l*8/PG ...], reduces them in that tree order, and the lanes
+// finish the tree with an xor butterfly (floating-point addition is commutative, so both
+// partners of an exchange obtain identical bits).  Every lane returns the full sum.
 __device__ __forceinline__ double pw_leaf8(const PatchReader& a, int lo, int n, int l) {
     if (n < 8) {
         double r = -0.0;
@@ -155,6 +135,8 @@ __device__ __forceinline__ double pw_leaf8(const PatchReader& a, int lo, int n, 
     for (int i = lim; i < n; ++i) t += a(lo + i);
     return t;
 }
+// Larger windows are halved (first half rounded down to a multiple of 8) and the halves summed,
+// as NumPy does.  Depth 3 covers n <= 1024, i.e. patch edges up to 31.
 template <int D>
 __device__ __forceinline__ double pw_sum8(const PatchReader& a, int lo, int n, int l) {
     if (n <= 128) return pw_leaf8(a, lo, n, l);
@@ -171,10 +153,10 @@ __device__ __forceinline__ double pw_sum8<0>(const PatchReader& a, int lo, int n
 
 // Confidence (criminisi_inpainter.py:114-127), data term (:129-214) and priority (:112) of one
 // front pixel, computed by PG cooperating lanes (l = lane index within the group; all PG lanes
-// must call this together and all receive the result).  ccur is the confidence map before
-// this iteration's update.
-__device__ __forceinline__ FrontEval eval_front_pixel(const Params& p, const int* grad,
-                                                      const double* ccur, int y, int x, int F,
+// must call this together and all receive the result).  conf is the confidence map before this
+// iteration's update, nb the pixel's 3x3 mask neighbourhood, F its front weight.
+__device__ __forceinline__ FrontEval eval_front_pixel(const Params& p, const View<int>& grad,
+                                                      const View<double>& conf, int y, int x, int F,
                                                       const int nb[9], int l) {
     const int H = p.H, W = p.W, half = p.half;
     const int r0 = imax(0, y - half), r1 = imin(y + half, H - 1);
@@ -182,7 +164,7 @@ __device__ __forceinline__ FrontEval eval_front_pixel(const Params& p, const int
     const int ph = r1 - r0 + 1, pw = c1 - c0 + 1;
     const int n = ph * pw;
     PatchReader rd;
-    rd.c = ccur; rd.W = W; rd.r0 = r0; rd.c0 = c0; rd.pw = pw;
+    rd.c = conf; rd.r0 = r0; rd.c0 = c0; rd.pw = pw;
     rd.inv = (65536u + (unsigned)pw - 1u) / (unsigned)pw;
     FrontEval out;
     out.cnew = pw_sum8<3>(rd, 0, n, l) / (double)p.psq;
@@ -204,7 +186,7 @@ __device__ __forceinline__ FrontEval eval_front_pixel(const Params& p, const int
     for (int e = l; e < n; e += PG) {
         const unsigned q = ((unsigned)e * rd.inv) >> 16;
         const int col = e - (int)q * pw;
-        const int gpk = grad[(size_t)(r0 + (int)q) * W + c0 + col];
+        const int gpk = grad.at(r0 + (int)q, c0 + col);
         const int gy2 = (int)(short)(gpk & 0xffff), gx2 = gpk >> 16;
         const int m = gy2 * gy2 + gx2 * gx2;
         if (m > best) { best = m; beste = e; bpk = gpk; }
@@ -299,27 +281,33 @@ __global__ __launch_bounds__(256) void k_init_pixels(Params p, int first) {
     if (threadIdx.x == 0 && cnt) atomicAdd(&p.st[b].remaining, cnt);
 }
 
-// Gradient field and window-validity map; needs the normalised mask of the whole image.
+// Gradient field, window-validity map and the per-tile count of front pixels; needs the
+// normalised mask of the whole image.  One block per 16x16 tile.
 __global__ __launch_bounds__(256) void k_init_fields(Params p, int first) {
     const int b = first + blockIdx.z;
     const int y = blockIdx.y * CRIM_TILE + (threadIdx.x >> 4);
     const int x = blockIdx.x * CRIM_TILE + (threadIdx.x & 15);
-    if (y >= p.H || x >= p.W) return;
     const size_t HW = (size_t)p.H * p.W;
     const uint8_t* mk = p.mask + b * HW;
-    p.grad[b * HW + (size_t)y * p.W + x] = grad_packed(p.grey + b * HW, mk, p.H, p.W, y, x);
-    int inv = 1;
-    if (y <= p.H - p.P && x <= p.W - p.P) {
-        inv = 0;
-        for (int i = 0; i < p.P && !inv; ++i)
-            for (int j = 0; j < p.P; ++j)
-                if (mk[(size_t)(y + i) * p.W + x + j]) { inv = 1; break; }
+    int isfront = 0;
+    if (y < p.H && x < p.W) {
+        p.grad[b * HW + (size_t)y * p.W + x] = grad_packed(p.grey + b * HW, mk, p.H, p.W, y, x);
+        int inv = 1;
+        if (y <= p.H - p.P && x <= p.W - p.P) {
+            inv = 0;
+            for (int i = 0; i < p.P && !inv; ++i)
+                for (int j = 0; j < p.P; ++j)
+                    if (mk[(size_t)(y + i) * p.W + x + j]) { inv = 1; break; }
+        }
+        p.invalid[((size_t)b * p.H + y) * p.Wi + x] = (uint8_t)inv;
+        int nb[9];
+        isfront = front_weight(mk, p.H, p.W, y, x, nb) > 0;
     }
-    p.invalid[((size_t)b * p.H + y) * p.Wi + x] = (uint8_t)inv;
-    int nb[9];
-    if (front_weight(mk, p.H, p.W, y, x, nb) > 0) {
-        const unsigned k = atomicAdd(&p.st[b].fcount, 1u);
-        p.flist[(size_t)b * 2 * p.fcap + k] = y * p.W + x;
+    const int cnt = __syncthreads_count(isfront);
+    if (threadIdx.x == 0) {
+        const int tile = blockIdx.y * p.tnx + blockIdx.x;
+        p.tfront[(size_t)b * p.tnx * p.tny + tile] = cnt;
+        if (cnt) p.tlist[(size_t)b * p.tcap + atomicAdd(&p.st[b].tcount, 1u)] = tile;
     }
 }
 
@@ -328,7 +316,7 @@ __global__ void k_init_state(Params p, int first, int count) {
     if (i >= count) return;
     ImgState* s = p.st + first + i;
     s->iter = 0; s->live = 1; s->cur = 0; s->remaining = 0;
-    s->fcount = 0; s->fsel = 0;
+    s->tcount = 0;
     s->pcount = 0; s->scount = 0; s->stalled = 0; s->bound = 0x7fffffff;
     p.desc[first + i].live = 0;
 }
@@ -341,92 +329,155 @@ __device__ __forceinline__ bool better_prio(double pa, int ia, double pb, int ib
     return pa > pb || (pa == pb && ia < ib);
 }
 
-// The fill front is kept as a per-image list of pixel positions.  A known pixel joins the front
-// when a diagonal neighbour is masked and leaves it when the last such neighbour is filled; the
-// mask only shrinks, so a pixel enters the list at most once (at upload, or when it is filled
-// next to still-masked pixels) and stale entries are simply skipped until the next compaction.
+// The priority stage works on 16x16 pixel tiles that hold at least one front pixel.  tfront
+// counts the front pixels of every tile exactly (maintained by k_update); tlist names the tiles
+// to visit.  A tile is appended when its count leaves zero and stays listed, possibly with a zero
+// count or twice, until the next rebuild; visiting such an entry is harmless.
 
-// Drops the entries that are no longer on the front (one block per image).
-__global__ __launch_bounds__(1024) void k_compact(Params p) {
+// Rebuilds the tile list from the counts (one block per image).
+__global__ __launch_bounds__(256) void k_tiles(Params p) {
     const int b = blockIdx.x;
     ImgState* st = p.st + b;
     if (!st->live) return;
     __shared__ unsigned s_n;
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
-    const size_t HW = (size_t)p.H * p.W;
-    const uint8_t* mask = p.mask + b * HW;
-    const int sel = st->fsel;
-    const int* src = p.flist + ((size_t)b * 2 + sel) * p.fcap;
-    int* dst = p.flist + ((size_t)b * 2 + (sel ^ 1)) * p.fcap;
-    const unsigned n = st->fcount;
-    for (unsigned e = threadIdx.x; e < n; e += 1024) {
-        const int pos = src[e];
-        const int y = pos / p.W, x = pos - y * p.W;
-        int nb[9];
-        if (front_weight(mask, p.H, p.W, y, x, nb) > 0) dst[atomicAdd(&s_n, 1u)] = pos;
-    }
+    const int nt = p.tnx * p.tny;
+    const int* tf = p.tfront + (size_t)b * nt;
+    int* tl = p.tlist + (size_t)b * p.tcap;
+    for (int t = threadIdx.x; t < nt; t += 256)
+        if (tf[t] > 0) tl[atomicAdd(&s_n, 1u)] = t;
     __syncthreads();
-    if (threadIdx.x == 0) { st->fcount = s_n; st->fsel = sel ^ 1; }
+    if (threadIdx.x == 0) st->tcount = s_n;
 }
 
-// grid (pgrid, B): groups of PG lanes walk the image's front list; every live entry gets its new
-// confidence (written to the other confidence buffer: the update is Jacobi-style, :115-127) and
-// its priority; each block emits its best (priority, position).
-__global__ __launch_bounds__(256) void k_priority(Params p) {
+// grid (pgrid, B), one wave per block; block g of image b walks entries g, g + pgrid, ... of
+// that image's tile list.  Per tile: the confidence and gradient fields of the tile grown by
+// the patch half-width and the mask grown by one pixel are staged in LDS; front pixels are
+// compacted; groups of PG lanes evaluate one front pixel each from LDS.  Every front pixel gets
+// its new confidence (written to the other confidence buffer: the update is Jacobi-style,
+// :115-127) and its priority; the block emits its best (priority, position).
+__global__ __launch_bounds__(64) void k_priority(Params p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.y;
     ImgState* st = p.st + b;
     STAMP(0);
     if (!st->live) return;
-    const int H = p.H, W = p.W;
+    const int H = p.H, W = p.W, half = p.half;
     const size_t HW = (size_t)H * W;
-    const int n = (int)st->fcount;
+    const int nt = (int)st->tcount;
     STAMP(1);
-    constexpr int GPB = 256 / PG;
-    if ((int)blockIdx.x * GPB >= n) return;
-    const int* fl = p.flist + ((size_t)b * 2 + st->fsel) * p.fcap;
+    if ((int)blockIdx.x >= nt) return;
+    const int RS = CRIM_TILE + 2 * half;          // edge of the staged region
+    const int MS = CRIM_TILE + 2;                 // edge of the staged mask
+    double* s_conf = (double*)smem;
+    int* s_grad = (int*)(s_conf + RS * RS);
+    int* s_list = s_grad + RS * RS;
+    uint8_t* s_mask = (uint8_t*)(s_list + CRIM_TILE * CRIM_TILE);
+    const int* tl = p.tlist + (size_t)b * p.tcap;
+    const int* tf = p.tfront + (size_t)b * p.tnx * p.tny;
     const int cur = st->cur;
     const double* ccur = p.conf + ((size_t)b * 2 + cur) * HW;
     double* cnxt = p.conf + ((size_t)b * 2 + (cur ^ 1)) * HW;
     const uint8_t* mask = p.mask + b * HW;
     const int* grad = p.grad + b * HW;
-
-    __shared__ double s_bp[4];
-    __shared__ int s_bi[4];
-    const int tid = threadIdx.x;
-    const int grp = tid / PG, l = tid % PG;
+    const int lane = threadIdx.x;
+    const int grp = lane / PG, l = lane % PG;
     double bestP = -1.0;
     int bestI = 0x7fffffff;
-    for (int e = blockIdx.x * GPB + grp; e < n; e += gridDim.x * GPB) {
-        const int pos = fl[e];
-        const int fy = pos / W, fx = pos - fy * W;
-        int fnb[9];
-        const int fF = front_weight(mask, H, W, fy, fx, fnb);
-        if (fF == 0) continue;   // left the front since the last compaction
-        const FrontEval ev = eval_front_pixel(p, grad, ccur, fy, fx, fF, fnb, l);
-        if (l == 0) {
-            cnxt[pos] = ev.cnew;
-            if (better_prio(ev.prio, pos, bestP, bestI)) { bestP = ev.prio; bestI = pos; }
+
+    for (int ti = blockIdx.x; ti < nt; ti += gridDim.x) {
+        const int tile = tl[ti];
+        if (tf[tile] <= 0) continue;              // block-uniform
+        const int tY = tile / p.tnx, tX = tile - tY * p.tnx;
+        const int ty0 = tY * CRIM_TILE, tx0 = tX * CRIM_TILE;
+        const int ry0 = ty0 - half, rx0 = tx0 - half;
+        // batches of 8 elements per lane so that 16 loads are in flight before the first store
+        for (int i0 = lane; i0 < RS * RS; i0 += 64 * 8) {
+            double cv[8];
+            int gv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = i0 + 64 * k;
+                const int yy = ry0 + i / RS, xx = rx0 + i % RS;
+                cv[k] = 0.0;
+                gv[k] = 0;
+                if (i < RS * RS && yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                    cv[k] = ccur[(size_t)yy * W + xx];
+                    gv[k] = grad[(size_t)yy * W + xx];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = i0 + 64 * k;
+                if (i < RS * RS) { s_conf[i] = cv[k]; s_grad[i] = gv[k]; }
+            }
         }
+        {
+            uint8_t mv[6];   // MS*MS = 324 <= 6*64
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const int i = lane + 64 * k;
+                const int yy = ty0 - 1 + i / MS, xx = tx0 - 1 + i % MS;
+                mv[k] = 0;
+                if (i < MS * MS && yy >= -1 && yy <= H && xx >= -1 && xx <= W)
+                    mv[k] = mask[(size_t)reflect101(yy, H) * W + reflect101(xx, W)];
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const int i = lane + 64 * k;
+                if (i < MS * MS) s_mask[i] = mv[k];
+            }
+        }
+        __syncthreads();
+        int n = 0;
+        for (int pass = 0; pass < CRIM_TILE * CRIM_TILE / 64; ++pass) {
+            const int pi = pass * 64 + lane;
+            const int py = pi >> 4, px = pi & 15;
+            bool isf = false;
+            if (ty0 + py < H && tx0 + px < W) {
+                const uint8_t* m0 = s_mask + py * MS + px;   // top-left of the 3x3 neighbourhood
+                isf = m0[MS + 1] == 0 && (m0[0] + m0[2] + m0[2 * MS] + m0[2 * MS + 2]) > 0;
+            }
+            const unsigned long long bal = __ballot(isf);
+            if (isf) s_list[n + __popcll(bal & ((1ull << lane) - 1ull))] = pi;
+            n += __popcll(bal);
+        }
+        __syncthreads();
+        View<double> vconf; vconf.base = s_conf; vconf.pitch = RS; vconf.oy = ry0; vconf.ox = rx0;
+        View<int> vgrad; vgrad.base = s_grad; vgrad.pitch = RS; vgrad.oy = ry0; vgrad.ox = rx0;
+        for (int e = grp; e < n; e += 64 / PG) {
+            const int pi = s_list[e];
+            const int py = pi >> 4, px = pi & 15;
+            const int fy = ty0 + py, fx = tx0 + px;
+            const uint8_t* m0 = s_mask + py * MS + px;
+            int nb[9];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) nb[a * 3 + c] = m0[a * MS + c];
+            const int F = front_from_nb(nb);
+            const FrontEval ev = eval_front_pixel(p, vgrad, vconf, fy, fx, F, nb, l);
+            if (l == 0) {
+                const int pos = fy * W + fx;
+                cnxt[pos] = ev.cnew;
+                if (better_prio(ev.prio, pos, bestP, bestI)) { bestP = ev.prio; bestI = pos; }
+            }
+        }
+        __syncthreads();   // the staging buffers are reused by the next tile
     }
     STAMP(2);
-    // block arg-max: highest priority, lowest row-major index on ties (np.argmax, :217)
+    // wave arg-max: highest priority, lowest row-major index on ties (np.argmax, :217)
     for (int off = 32; off > 0; off >>= 1) {
         const double op = __shfl_down(bestP, off);
         const int oi = __shfl_down(bestI, off);
         if (better_prio(op, oi, bestP, bestI)) { bestP = op; bestI = oi; }
     }
-    if ((tid & 63) == 0) { s_bp[tid >> 6] = bestP; s_bi[tid >> 6] = bestI; }
-    __syncthreads();
-    if (tid == 0) {
-        for (int w = 1; w < 4; ++w)
-            if (better_prio(s_bp[w], s_bi[w], bestP, bestI)) { bestP = s_bp[w]; bestI = s_bi[w]; }
-        if (bestP >= 0.0) {
-            const unsigned k = atomicAdd(&st->pcount, 1u);
-            PEntry e;
-            e.prio = bestP; e.pos = bestI; e.pad = 0;
-            p.plist[(size_t)b * p.pgrid + k] = e;
-        }
+    if (lane == 0 && bestP >= 0.0) {
+        const unsigned k = atomicAdd(&st->pcount, 1u);
+        PEntry e;
+        e.prio = bestP; e.pos = bestI; e.pad = 0;
+        p.plist[(size_t)b * p.pgrid + k] = e;
     }
     STAMP(3);
 }
@@ -448,7 +499,9 @@ __global__ __launch_bounds__(256) void k_fields(Params p, int b, uint8_t* front,
     const size_t i = (size_t)y * p.W + x;
     double dv = 0.001, pv = 0.0;   // off the front the gradient is zero: sqrt(0) + 0.001
     if (F > 0) {
-        const FrontEval ev = eval_front_pixel(p, p.grad + b * HW, ccur, y, x, F, nb, l);
+        View<double> vconf; vconf.base = ccur; vconf.pitch = p.W; vconf.oy = 0; vconf.ox = 0;
+        View<int> vgrad; vgrad.base = p.grad + b * HW; vgrad.pitch = p.W; vgrad.oy = 0; vgrad.ox = 0;
+        const FrontEval ev = eval_front_pixel(p, vgrad, vconf, y, x, F, nb, l);
         dv = ev.data;
         pv = ev.prio;
     }
@@ -729,16 +782,23 @@ __global__ __launch_bounds__(256) void k_search(Params p) {
                 for (int j = 0; j < ND; ++j) img[rr][j] = lds[ch][ty * R + rr][tx + j];
             const_u32_ptr t = tm + ch * (P * 4 * ND);
 #pragma unroll
-            for (int i = 0; i < P; ++i)
+            for (int i = 0; i < P; ++i) {
+                // Skipping all-zero template dwords (22 % of them on the 10 %-mask workload) with a
+                // wave-uniform branch per 4 dot products was measured 8 % SLOWER: kept branch-free.
+                int tv[4][ND];
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int j = 0; j < ND; ++j) tv[s][j] = (int)t[(i * 4 + s) * ND + j];
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
                     for (int j = 0; j < ND; ++j) {
-                        const int tv = (int)t[(i * 4 + s) * ND + j];
 #pragma unroll
                         for (int r = 0; r < R; ++r)
-                            accC[r][s] = __builtin_amdgcn_sdot4((int)img[r + i][j], tv, accC[r][s], false);
+                            accC[r][s] = __builtin_amdgcn_sdot4((int)img[r + i][j], tv[s][j], accC[r][s], false);
                     }
+            }
         }
 #pragma unroll 1
         for (int q = 0; q < 2; ++q) {
@@ -749,16 +809,21 @@ __global__ __launch_bounds__(256) void k_search(Params p) {
                 for (int j = 0; j < ND; ++j) img[rr][j] = lds[3 + q][ty * R + rr][tx + j];
             const_u32_ptr t = tm + (3 + q) * (P * 4 * ND);
 #pragma unroll
-            for (int i = 0; i < P; ++i)
+            for (int i = 0; i < P; ++i) {
+                uint32_t tv[4][ND];
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int j = 0; j < ND; ++j) tv[s][j] = t[(i * 4 + s) * ND + j];
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
                     for (int j = 0; j < ND; ++j) {
-                        const uint32_t tv = t[(i * 4 + s) * ND + j];
 #pragma unroll
                         for (int r = 0; r < R; ++r)
-                            accQ[r][s] = (int)__builtin_amdgcn_udot4(img[r + i][j], tv, (uint32_t)accQ[r][s], false);
+                            accQ[r][s] = (int)__builtin_amdgcn_udot4(img[r + i][j], tv[s][j], (uint32_t)accQ[r][s], false);
                     }
+            }
         }
         const int soff = d->soff;
 #pragma unroll
@@ -870,7 +935,8 @@ __global__ __launch_bounds__(256) void k_update(Params p) {
     __shared__ double s_cost;
     __shared__ int s_filled;
     __shared__ uint8_t s_px[PM * PM][9];   // source pixel: B,G,R, 5 planes, grey
-    __shared__ uint8_t s_m[MR * MR];
+    __shared__ uint8_t s_m[MR * MR];    // mask around the patch, updated as pixels are filled
+    __shared__ uint8_t s_m0[MR * MR];   // the same before this iteration's fill
     __shared__ uint8_t s_g[GR * GR];
     __shared__ unsigned s_fill[(PM * PM + 31) / 32];   // bit e: patch element e was filled
     __shared__ unsigned long long s_rb[MR][2];         // per snapshot row: bit j = pixel j masked
@@ -912,7 +978,7 @@ __global__ __launch_bounds__(256) void k_update(Params p) {
     uint8_t* planes = p.planes + (size_t)b * 5 * H * p.Wp;
     const size_t PS = (size_t)H * p.Wp;
     // loop state is read once, up front: thread 0 rewrites it at the end of this kernel
-    const int cur = st->cur, fsel = st->fsel;
+    const int cur = st->cur;
     double* cnxt = p.conf + ((size_t)b * 2 + (cur ^ 1)) * HW;
 
     // ---- snapshot: source pixels, the mask around the patch, the grey values around it
@@ -933,6 +999,7 @@ __global__ __launch_bounds__(256) void k_update(Params p) {
         uint8_t v = 1;   // beyond the image: a window reaching there is not a candidate
         if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = mask[(size_t)yy * W + xx];
         s_m[i * MR + j] = v;
+        s_m0[i * MR + j] = v;
     }
     const int gr0 = r0 - 2, gc0 = c0 - 2, grh = ph + 4, grw = pw + 4;
     for (int e = tid; e < grh * grw; e += 256) {
@@ -1007,18 +1074,37 @@ __global__ __launch_bounds__(256) void k_update(Params p) {
         const unsigned long long pm = (1ull << P) - 1ull;
         inv[(size_t)oy * p.Wi + ox] = (uint8_t)((w & pm) != 0);
     }
-    // ---- fill front: a filled pixel with a still-masked diagonal neighbour joins the list
+    // ---- per-tile front counts: only pixels within one pixel of the patch can join the front
+    // (a filled pixel next to still-masked ones) or leave it (its masked diagonal neighbours
+    // were all filled)
     {
-        auto M = [&](int y2, int x2) -> int {
+        auto MN = [&](int y2, int x2) -> int {
             return (int)s_m[(reflect101(y2, H) - mr0) * MR + (reflect101(x2, W) - mc0)];
         };
-        int* fl = p.flist + ((size_t)b * 2 + fsel) * p.fcap;
-        for (int e = tid; e < ph * pw; e += 256) {
-            if (!(s_fill[e >> 5] & (1u << (e & 31)))) continue;
-            const int i = e / pw, j = e - i * pw;
-            const int yy = r0 + i, xx = c0 + j;
-            if (M(yy - 1, xx - 1) + M(yy - 1, xx + 1) + M(yy + 1, xx - 1) + M(yy + 1, xx + 1) > 0)
-                fl[atomicAdd(&st->fcount, 1u)] = yy * W + xx;
+        auto MO = [&](int y2, int x2) -> int {
+            return (int)s_m0[(reflect101(y2, H) - mr0) * MR + (reflect101(x2, W) - mc0)];
+        };
+        int* tf = p.tfront + (size_t)b * p.tnx * p.tny;
+        int* tl = p.tlist + (size_t)b * p.tcap;
+        const int fh = ph + 2, fw = pw + 2;
+        for (int e = tid; e < fh * fw; e += 256) {
+            const int i = e / fw, j = e - i * fw;
+            const int yy = r0 - 1 + i, xx = c0 - 1 + j;
+            if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+            const bool fo = MO(yy, xx) == 0 &&
+                            MO(yy - 1, xx - 1) + MO(yy - 1, xx + 1) + MO(yy + 1, xx - 1) + MO(yy + 1, xx + 1) > 0;
+            const bool fn = MN(yy, xx) == 0 &&
+                            MN(yy - 1, xx - 1) + MN(yy - 1, xx + 1) + MN(yy + 1, xx - 1) + MN(yy + 1, xx + 1) > 0;
+            if (fo == fn) continue;
+            const int tile = (yy / CRIM_TILE) * p.tnx + xx / CRIM_TILE;
+            if (fn) {
+                if (atomicAdd(&tf[tile], 1) == 0) {
+                    const unsigned k = atomicAdd(&st->tcount, 1u);
+                    if (k < (unsigned)p.tcap) tl[k] = tile;
+                }
+            } else {
+                atomicSub(&tf[tile], 1);
+            }
         }
     }
     // ---- confidence buffers: the buffer that was current during this iteration is stale on this

@@ -21,8 +21,8 @@ struct ImgState {
     int live;        // 1 while the next iteration must run
     int cur;         // which of the two confidence buffers is current
     int remaining;   // masked pixels left
-    unsigned fcount; // entries in the current front list
-    int fsel;        // which of the two front-list buffers is current
+    unsigned tcount; // entries in the priority-stage tile list
+    int pad0;
     unsigned pcount; // entries in this image's priority partial list
     unsigned scount; // entries in this image's search partial list
     int stalled;     // an iteration filled nothing while pixels remained
@@ -86,8 +86,9 @@ struct Params {
     uint8_t* invalid;  // [B][H][Wi] 1: the P x P window at this origin holds a masked pixel
     ImgState* st;
     Desc* desc;
-    long fcap;         // capacity of one front-list buffer (H*W)
-    int* flist;        // [B][2][fcap] pixel positions on (or recently on) the fill front
+    int tcap;          // capacity of one image's tile list (twice the tile count)
+    int* tfront;       // [B][tny*tnx] front pixels per 16x16 tile
+    int* tlist;        // [B][tcap] tiles the priority stage visits
     PEntry* plist;     // [B][pgrid]
     SEntry* slist;     // [B][snx*sny]
     crim_iter_rec* trace;  // [B][trace_cap]
