@@ -5,6 +5,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -135,18 +136,27 @@ struct GraphSet {
     int iters = 0;
 };
 
+// A lane is a contiguous sub-batch that advances on its own stream: its latency-bound stages
+// (priority, select, update) overlap the VALU-bound search of the other lanes.
+struct Lane {
+    hipStream_t stream = nullptr;
+    Params prm;                     // engine parameters with b0 / B narrowed to this lane
+    std::vector<GraphSet> graphs;
+    long done = 0;                  // iterations launched in the current crim_run call
+};
+
 struct crim_engine {
     int device = 0;
     unsigned flags = 0;
     int patch_size = 0;
     Params prm;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;   // uploads, downloads, upload-time kernels
+    std::vector<Lane> lanes;
     uint16_t* d_gamma = nullptr;
     uint16_t* d_cbrt = nullptr;
     ImgState* h_state = nullptr;    // pinned mirror of prm.st
     std::vector<bool> uploaded;
     bool prepared = false;          // scan window, trace buffer and graphs match the uploads
-    std::vector<GraphSet> graphs;
     // profile accumulators
     std::vector<hipEvent_t> ev;     // pairs
     int ev_used = 0;
@@ -157,13 +167,14 @@ struct crim_engine {
 };
 
 static void free_graphs(crim_engine* h) {
-    for (auto& g : h->graphs)
-        if (g.exec) (void)hipGraphExecDestroy(g.exec);
-    h->graphs.clear();
+    for (auto& ln : h->lanes) {
+        for (auto& g : ln.graphs)
+            if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        ln.graphs.clear();
+    }
 }
 
-static void launch_search(crim_engine* h, hipStream_t s) {
-    const Params& p = h->prm;
+static void launch_search(const Params& p, hipStream_t s) {
     dim3 grid(p.snx, p.sny, p.B), block(256);
     if (p.generic) {
         hipLaunchKernelGGL(k_search_generic, grid, block, 0, s, p);
@@ -183,10 +194,8 @@ static void launch_search(crim_engine* h, hipStream_t s) {
 
 static bool has_fast_search(int P) { return P >= 3 && P <= 15 && (P & 1); }
 
-// One iteration of criminisi_inpainter.py:51-83 as four dependent launches.
 // Tile-list rebuild: stale entries only cost a skipped lookup, so it runs rarely.
-static void launch_compact(crim_engine* h, hipStream_t s) {
-    const Params& p = h->prm;
+static void launch_compact(const Params& p, hipStream_t s) {
     hipLaunchKernelGGL(k_tiles, dim3(p.B), dim3(256), 0, s, p);
 }
 
@@ -197,24 +206,26 @@ static size_t priority_lds_bytes(const Params& p) {
 
 #define COMPACT_PERIOD 16
 
-static void launch_iteration(crim_engine* h, hipStream_t s, bool profile) {
-    const Params& p = h->prm;
+// One iteration of criminisi_inpainter.py:51-83 as four dependent launches.  ev0/ev1, when
+// given, bracket the search launch.
+static void launch_iteration(const Params& p, hipStream_t s, hipEvent_t ev0 = nullptr,
+                             hipEvent_t ev1 = nullptr) {
     hipLaunchKernelGGL(k_priority, dim3(p.pgrid, p.B), dim3(64), priority_lds_bytes(p), s, p);
     hipLaunchKernelGGL(k_select, dim3(p.B), dim3(256), 0, s, p);
-    if (profile) (void)hipEventRecord(h->ev[2 * h->ev_used], s);
-    launch_search(h, s);
-    if (profile) (void)hipEventRecord(h->ev[2 * h->ev_used + 1], s);
+    if (ev0) (void)hipEventRecord(ev0, s);
+    launch_search(p, s);
+    if (ev1) (void)hipEventRecord(ev1, s);
     hipLaunchKernelGGL(k_update, dim3(p.B), dim3(256), 0, s, p);
 }
 
-static int build_graph(crim_engine* h, int iters, GraphSet* out) {
+static int build_graph(Lane& ln, int iters, GraphSet* out) {
     hipGraph_t graph = nullptr;
-    HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    HIP_TRY(hipStreamBeginCapture(ln.stream, hipStreamCaptureModeThreadLocal));
     for (int i = 0; i < iters; ++i) {
-        if (i > 0 && i % COMPACT_PERIOD == 0) launch_compact(h, h->stream);
-        launch_iteration(h, h->stream, false);
+        if (i > 0 && i % COMPACT_PERIOD == 0) launch_compact(ln.prm, ln.stream);
+        launch_iteration(ln.prm, ln.stream);
     }
-    HIP_TRY(hipStreamEndCapture(h->stream, &graph));
+    HIP_TRY(hipStreamEndCapture(ln.stream, &graph));
     hipGraphExec_t exec = nullptr;
     hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
@@ -244,7 +255,11 @@ extern "C" void crim_destroy(crim_t* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (auto& ln : h->lanes)
+        if (ln.stream) (void)hipStreamSynchronize(ln.stream);
     free_graphs(h);
+    for (auto& ln : h->lanes)
+        if (ln.stream) (void)hipStreamDestroy(ln.stream);
     for (auto e : h->ev) (void)hipEventDestroy(e);
     Params& p = h->prm;
     void* bufs[] = {p.bgr, p.planes, p.mask, p.grey, p.grad, p.conf, p.invalid, p.tfront, p.tlist, p.st,
@@ -310,6 +325,7 @@ extern "C" int crim_create_batch(int batch, int H, int W, int patch_size, int de
     alloc((void**)&p.st, Bz * sizeof(ImgState));
     alloc((void**)&p.desc, Bz * sizeof(Desc));
     p.pgrid = std::min(std::min(2048, p.tnx * p.tny), std::max(16, 16384 / batch));
+    p.b0 = 0;
     alloc((void**)&p.plist, Bz * p.pgrid * sizeof(PEntry));
     alloc((void**)&p.slist, Bz * p.snx * p.sny * sizeof(SEntry));
     alloc((void**)&p.dbg, 64 * sizeof(long long));
@@ -333,6 +349,24 @@ extern "C" int crim_create_batch(int batch, int H, int W, int patch_size, int de
     p.gamma_tab = h->d_gamma;
     p.cbrt_tab = h->d_cbrt;
     h->uploaded.assign(batch, false);
+    {
+        // Lanes: sub-batches on their own streams.  One lane when profiling (the event pairs
+        // must bracket exactly one search launch) or when the batch is small.  Measured on
+        // 256 images of 256x256: 2 lanes +9 % images/s over 1, 4 lanes -17 % (the streams share
+        // two hardware queues and every lane adds its own latency-bound launches).
+        int nl = batch >= 32 ? 2 : 1;
+        if (const char* env = getenv("CRIM_LANES")) nl = atoi(env);
+        if (h->flags & CRIM_FLAG_PROFILE) nl = 1;
+        nl = std::max(1, std::min(nl, std::min(batch, 16)));
+        h->lanes.resize(nl);
+        for (int i = 0; i < nl; ++i) {
+            Lane& ln = h->lanes[i];
+            HIP_TRY(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+            ln.prm = p;
+            ln.prm.b0 = (int)((long)batch * i / nl);
+            ln.prm.B = (int)((long)batch * (i + 1) / nl) - ln.prm.b0;
+        }
+    }
     if (h->flags & CRIM_FLAG_PROFILE) {
         h->ev.resize(2 * 64);
         h->ev_evals.resize(64);
@@ -424,15 +458,22 @@ static int prepare(crim_engine* h) {
     }
     const bool changed = memcmp(&q, &p, sizeof(Params)) != 0;
     p = q;
-    if (changed || h->graphs.empty()) {
+    bool have_graphs = true;
+    for (auto& ln : h->lanes) have_graphs = have_graphs && !ln.graphs.empty();
+    if (changed || !have_graphs) {
         free_graphs(h);
-        if (!(h->flags & CRIM_FLAG_EAGER)) {
+        for (auto& ln : h->lanes) {
+            const int b0 = ln.prm.b0, nb = ln.prm.B;
+            ln.prm = p;
+            ln.prm.b0 = b0;
+            ln.prm.B = nb;
+            if (h->flags & CRIM_FLAG_EAGER) continue;
             static const int sizes[3] = {64, 8, 1};
             for (int s : sizes) {
                 GraphSet g;
-                const int rc = build_graph(h, s, &g);
+                const int rc = build_graph(ln, s, &g);
                 if (rc) return rc;
-                h->graphs.push_back(g);
+                ln.graphs.push_back(g);
             }
         }
     }
@@ -463,54 +504,62 @@ extern "C" int crim_run(crim_t* h, long max_iters, long* iters_done, long* remai
     Params& p = h->prm;
     const bool profile = (h->flags & CRIM_FLAG_PROFILE) != 0;
     const bool eager = (h->flags & CRIM_FLAG_EAGER) != 0;
-    long done = 0;
+    for (auto& ln : h->lanes) ln.done = 0;
     int rc = CRIM_OK;
     for (;;) {
+        // every lane is idle here
         HIP_TRY(hipMemcpyAsync(h->h_state, p.st, (size_t)p.B * sizeof(ImgState), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
-        long need = 0, live = 0;
-        for (int i = 0; i < p.B; ++i) {
-            const ImgState& s = h->h_state[i];
-            if (s.stalled) rc = CRIM_ERR_NO_PROGRESS;
-            if (!s.live) continue;
-            ++live;
-            // every iteration fills at most P*P pixels: a lower bound on what is still needed
-            const long lb = std::max(1L, ((long)s.remaining + p.P * p.P - 1) / (p.P * p.P));
-            need = std::max(need, lb);
-        }
-        if (rc || live == 0) break;
-        if (max_iters > 0) {
-            if (done >= max_iters) break;
-            need = std::min(need, max_iters - done);
-        }
-        if (profile) {
-            // one iteration per round so that the number of live images per launch is known
-            const double evals = (double)live * (double)std::max(p.H - p.P + 1, 0) * (double)std::max(p.W - p.P + 1, 0);
-            h->ev_evals[h->ev_used] = evals;
-            if (done > 0 && done % COMPACT_PERIOD == 0) launch_compact(h, h->stream);
-            launch_iteration(h, h->stream, true);
-            ++h->ev_used;
-            if (h->ev_used == (int)h->ev_evals.size()) {
-                const int r2 = flush_profile(h);
-                if (r2) return r2;
+        for (int i = 0; i < p.B; ++i)
+            if (h->h_state[i].stalled) rc = CRIM_ERR_NO_PROGRESS;
+        if (rc) break;
+        bool any = false;
+        for (auto& ln : h->lanes) {
+            const Params& lp = ln.prm;
+            long need = 0, live = 0;
+            for (int i = lp.b0; i < lp.b0 + lp.B; ++i) {
+                const ImgState& s = h->h_state[i];
+                if (!s.live) continue;
+                ++live;
+                // every iteration fills at most P*P pixels: a lower bound on what is still needed
+                const long lb = std::max(1L, ((long)s.remaining + p.P * p.P - 1) / (p.P * p.P));
+                need = std::max(need, lb);
             }
-            done += 1;
-        } else if (eager) {
-            for (long i = 0; i < need; ++i) {
-                if ((done + i) > 0 && (done + i) % COMPACT_PERIOD == 0) launch_compact(h, h->stream);
-                launch_iteration(h, h->stream, false);
-            }
-            done += need;
-        } else {
-            long left = need;
-            for (auto& g : h->graphs)
-                while (left >= g.iters) {
-                    HIP_TRY(hipGraphLaunch(g.exec, h->stream));
-                    left -= g.iters;
+            if (live == 0) continue;
+            if (max_iters > 0) need = std::min(need, max_iters - ln.done);
+            if (need <= 0) continue;
+            any = true;
+            if (profile) {
+                // one iteration per round so that the number of live images per launch is known
+                const double evals = (double)live * (double)std::max(p.H - p.P + 1, 0) * (double)std::max(p.W - p.P + 1, 0);
+                h->ev_evals[h->ev_used] = evals;
+                if (ln.done > 0 && ln.done % COMPACT_PERIOD == 0) launch_compact(lp, ln.stream);
+                launch_iteration(lp, ln.stream, h->ev[2 * h->ev_used], h->ev[2 * h->ev_used + 1]);
+                ++h->ev_used;
+                if (h->ev_used == (int)h->ev_evals.size()) {
+                    const int r2 = flush_profile(h);
+                    if (r2) return r2;
                 }
-            done += need;
+                ln.done += 1;
+            } else if (eager) {
+                for (long i = 0; i < need; ++i) {
+                    if ((ln.done + i) > 0 && (ln.done + i) % COMPACT_PERIOD == 0) launch_compact(lp, ln.stream);
+                    launch_iteration(lp, ln.stream);
+                }
+                ln.done += need;
+            } else {
+                long left = need;
+                for (auto& g : ln.graphs)
+                    while (left >= g.iters) {
+                        HIP_TRY(hipGraphLaunch(g.exec, ln.stream));
+                        left -= g.iters;
+                    }
+                ln.done += need;
+            }
         }
         HIP_TRY(hipGetLastError());
+        if (!any) break;
+        for (auto& ln : h->lanes) HIP_TRY(hipStreamSynchronize(ln.stream));
     }
     if (profile) {
         const int r2 = flush_profile(h);

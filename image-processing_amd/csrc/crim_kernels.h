@@ -336,7 +336,7 @@ __device__ __forceinline__ bool better_prio(double pa, int ia, double pb, int ib
 
 // Rebuilds the tile list from the counts (one block per image).
 __global__ __launch_bounds__(256) void k_tiles(Params p) {
-    const int b = blockIdx.x;
+    const int b = p.b0 + blockIdx.x;
     ImgState* st = p.st + b;
     if (!st->live) return;
     __shared__ unsigned s_n;
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void k_tiles(Params p) {
 // :115-127) and its priority; the block emits its best (priority, position).
 __global__ __launch_bounds__(64) void k_priority(Params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int b = blockIdx.y;
+    const int b = p.b0 + blockIdx.y;
     ImgState* st = p.st + b;
     STAMP(0);
     if (!st->live) return;
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(256) void k_fields(Params p, int b, uint8_t* front,
 // ------------------------------------------------------------------------------------------
 
 __global__ __launch_bounds__(256) void k_select(Params p) {
-    const int b = blockIdx.x;
+    const int b = p.b0 + blockIdx.x;
     ImgState* st = p.st + b;
     Desc* d = p.desc + b;
     const int tid = threadIdx.x;
@@ -700,7 +700,7 @@ __global__ __launch_bounds__(256) void k_search(Params p) {
     __shared__ unsigned s_i[4];
     __shared__ int s_bound;
 
-    const int b = blockIdx.z;
+    const int b = p.b0 + blockIdx.z;
     const Desc* __restrict__ d = p.desc + b;
     if (!d->live) return;
     const int ncy = d->ncy, ncx = d->ncx;
@@ -872,7 +872,7 @@ __global__ __launch_bounds__(256) void k_search(Params p) {
 __global__ __launch_bounds__(256) void k_search_generic(Params p) {
     __shared__ double s_c[4];
     __shared__ unsigned s_i[4];
-    const int b = blockIdx.z;
+    const int b = p.b0 + blockIdx.z;
     const Desc* __restrict__ d = p.desc + b;
     if (!d->live) return;
     const int ncy = d->ncy, ncx = d->ncx;
@@ -918,7 +918,7 @@ __global__ __launch_bounds__(256) void k_search_generic(Params p) {
 // ------------------------------------------------------------------------------------------
 
 __global__ __launch_bounds__(256) void k_update(Params p) {
-    const int b = blockIdx.x;
+    const int b = p.b0 + blockIdx.x;
     ImgState* st = p.st + b;
     if (!st->live) return;
     const Desc* __restrict__ d = p.desc + b;

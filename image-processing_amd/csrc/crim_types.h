@@ -65,7 +65,8 @@ struct Desc {
 };
 
 struct Params {
-    int B, H, W;
+    int B, H, W;  // B: images covered by a launch with these parameters
+    int b0;       // first image covered (iteration kernels); upload-time kernels take `first`
     int P;        // patch edge 2*((patch_size-1)/2)+1
     int half;
     int psq;      // patch_size squared: the confidence divisor
