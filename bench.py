@@ -46,6 +46,21 @@ def make_batch(batch, rank):
     return imgs, masks
 
 
+def pmc_traffic_per_launch():
+    """HBM-side bytes per search launch from the committed rocprofv3 PMC passes of this same
+    command (FETCH_SIZE and WRITE_SIZE are collected in separate runs, tools/pmc_passes.sh; they
+    cannot be read from inside the benchmark).  FETCH_SIZE is doubled: the search stages its
+    tiles with 16-byte-per-lane coalesced loads, which gfx950 tallies at half their bytes.
+    None when no PMC summary is present."""
+    path = os.path.join(ROOT, "profiles", "pmc_search_latest.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return (2.0 * d["FETCH_SIZE_KB_per_launch"] + d["WRITE_SIZE_KB_per_launch"]) * 1024.0
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def _cpu_one(args):
     from oracle import c_oracle
     img, mask = args
@@ -54,7 +69,7 @@ def _cpu_one(args):
     return time.time() - t, n
 
 
-def cpu_baseline(imgs, masks, budget_images_per_core=2):
+def cpu_baseline(imgs, masks, budget_images_per_core=4):
     """C oracle over a bounded sample, one image per task on a process pool."""
     import multiprocessing as mp
     from oracle import c_oracle
@@ -174,16 +189,18 @@ def main():
             ms, launches, evals = pe.profile()
         macs = evals * PATCH * PATCH * 3
         achieved = macs / (ms * 1e-3) / 1e12
+        traffic = pmc_traffic_per_launch()
         result["evals_per_s_per_gpu"] = evals / (ms * 1e-3)
         result["roofline"] = {
             "bound": "valu", "kernel": "k_search<9>",
             "achieved": achieved, "peak": VALU_DOT4_PEAK_TMACS, "unit": "TMAC/s",
-            "frac": achieved / VALU_DOT4_PEAK_TMACS, "traffic": None,
+            "frac": achieved / VALU_DOT4_PEAK_TMACS, "traffic": traffic,
             "avg_launch_us": 1e3 * ms / max(launches, 1), "launches": launches,
             "algorithmic_macs_per_launch": macs / max(launches, 1),
             "note": "search is VALU-bound (8-bit dot products), neither HBM nor MFMA; algorithmic "
-                    "work = windows scored x 9*9*3 MAC; peak = v_dot4 ceiling 256 CU x 64 lanes x 4 "
-                    "MAC x 2.4 GHz",
+                    "work = windows scored x 9*9*3 MAC per launch (one launch covers one lane = half "
+                    "the batch); peak = v_dot4 ceiling 256 CU x 64 lanes x 4 MAC x 2.4 GHz; traffic = "
+                    "bytes per launch from the committed PMC passes (profiles/), cache resident",
         }
     if cpu is not None:
         result["cpu_baseline"] = cpu

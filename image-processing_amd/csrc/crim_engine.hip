@@ -350,13 +350,11 @@ extern "C" int crim_create_batch(int batch, int H, int W, int patch_size, int de
     p.cbrt_tab = h->d_cbrt;
     h->uploaded.assign(batch, false);
     {
-        // Lanes: sub-batches on their own streams.  One lane when profiling (the event pairs
-        // must bracket exactly one search launch) or when the batch is small.  Measured on
+        // Lanes: sub-batches on their own streams (one lane when the batch is small).  Measured on
         // 256 images of 256x256: 2 lanes +9 % images/s over 1, 4 lanes -17 % (the streams share
         // two hardware queues and every lane adds its own latency-bound launches).
         int nl = batch >= 32 ? 2 : 1;
         if (const char* env = getenv("CRIM_LANES")) nl = atoi(env);
-        if (h->flags & CRIM_FLAG_PROFILE) nl = 1;
         nl = std::max(1, std::min(nl, std::min(batch, 16)));
         h->lanes.resize(nl);
         for (int i = 0; i < nl; ++i) {

@@ -1,0 +1,29 @@
+#!/bin/bash
+# Separate rocprofv3 PMC passes over a short bench run (one counter group per run, no tracing
+# domains beside it).  Outputs under gpurun_out/pmc_<name>/.
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+run() {
+  name=$1; shift
+  timeout -s KILL 150 rocprofv3 --pmc "$@" --output-format csv -d $R/gpurun_out/pmc_$name -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > $R/gpurun_out/pmc_$name.log 2>&1
+  echo "pass $name exit=$?"
+}
+run valu SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY || exit 1
+run lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_UNALIGNED_STALL SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_ACTIVE_INST_ANY || exit 1
+run fetch FETCH_SIZE || exit 1
+run write WRITE_SIZE || exit 1
+run grbm GRBM_GUI_ACTIVE GRBM_COUNT || exit 1
+python3 - <<PY
+import csv, glob, collections
+for name in ("valu", "lds", "fetch", "write", "grbm"):
+    files = glob.glob("$R/gpurun_out/pmc_%s/*/*counter_collection.csv" % name)
+    if not files:
+        print(name, "no counter file"); continue
+    agg = collections.defaultdict(lambda: collections.defaultdict(float)); calls = collections.Counter()
+    for r in csv.DictReader(open(files[0])):
+        k = r["Kernel_Name"].split("(")[0]
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); 
+    for k in agg:
+        if "k_search" in k or k in ("k_priority", "k_update", "k_select"):
+            print(name, k, {c: round(v, 1) for c, v in agg[k].items()})
+PY
