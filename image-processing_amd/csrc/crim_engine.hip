@@ -534,6 +534,8 @@ extern "C" int crim_run(crim_t* h, long max_iters, long* iters_done, long* remai
                 if (ln.done > 0 && ln.done % COMPACT_PERIOD == 0) launch_compact(lp, ln.stream);
                 launch_iteration(lp, ln.stream, h->ev[2 * h->ev_used], h->ev[2 * h->ev_used + 1]);
                 ++h->ev_used;
+                // the bracketed launch must not share the GPU with another lane's kernels
+                HIP_TRY(hipStreamSynchronize(ln.stream));
                 if (h->ev_used == (int)h->ev_evals.size()) {
                     const int r2 = flush_profile(h);
                     if (r2) return r2;

@@ -740,6 +740,8 @@ __global__ __launch_bounds__(256) void k_search(Params p) {
                     vbits |= 1u << (r * 4 + s);
         }
     }
+    // (Compacting the live 4x4 origin groups so that they fill whole waves was measured: no gain,
+    // 57 us vs 56 us per launch of 128 images with a 10 % mask.)
     if (!__syncthreads_or(vbits != 0)) return;
 
     // stage the five byte planes of this tile (zero beyond the image): 16-byte chunks, all of a

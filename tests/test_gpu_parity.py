@@ -263,3 +263,63 @@ def test_full_size_properties_256():
     oout, oconf, _, otr, n = c_oracle.run(img, m, 9)
     assert n == len(tr) and np.array_equal(out, oout) and np.array_equal(conf, oconf)
     assert np.array_equal(tr, otr.astype(capi.ITER_REC_DTYPE))
+
+
+def test_random_stress_sweep():
+    """Many small random cases (sizes, patch sizes, mask shapes incl. borders, noise / smooth /
+    flat images): every one must match the oracle bit for bit."""
+    rng = np.random.default_rng(31337)
+    for k in range(48):
+        H = int(rng.integers(20, 90))
+        W = int(rng.integers(20, 90))
+        p = int(rng.choice([3, 4, 5, 7, 9, 9, 9, 11, 13, 15, 17]))
+        kind = k % 4
+        if kind == 0:
+            img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        elif kind == 1:
+            img = crim_synth.xray_like(H, W, 9000 + k, colour=True)
+        elif kind == 2:
+            img = crim_synth.xray_like(H, W, 9000 + k, colour=False)
+        else:
+            img = np.full((H, W, 3), int(rng.integers(0, 256)), np.uint8)
+            img[:, W // 2:] = int(rng.integers(0, 256))
+        m = np.zeros((H, W), np.uint8)
+        for _ in range(int(rng.integers(1, 5))):
+            h = int(rng.integers(1, max(2, H // 3)))
+            w = int(rng.integers(1, max(2, W // 3)))
+            y0 = int(rng.integers(0, H - h + 1))
+            x0 = int(rng.integers(0, W - w + 1))
+            m[y0:y0 + h, x0:x0 + w] = 1
+        if k % 5 == 0:
+            m[rng.random((H, W)) < 0.02] = 1        # salt: isolated masked pixels
+        if m.all():
+            m[0, 0] = 0
+        try:
+            assert_same_as_oracle(img, m, p)
+        except AssertionError as e:
+            raise AssertionError("case %d (H=%d W=%d p=%d kind=%d): %s" % (k, H, W, p, kind, e))
+
+
+def test_512_prefix_and_properties():
+    """BASELINE configs[2] shape (512x512x3, 10 % mask, patch 9): the first 24 iterations against
+    the oracle, then the full run through size-independent properties."""
+    img = crim_synth.xray_like(512, 512, 3001, colour=True)
+    m = crim_synth.blob_mask(512, 512, 3001, fraction=0.10, margin=9)
+    oout, oconf, omask, otr, n = c_oracle.run(img, m, 9, max_iters=24)
+    with capi.Engine(512, 512, 9) as eng:
+        eng.upload(img, m)
+        eng.run(max_iters=24)
+        out, conf, msk = eng.download(want_conf=True, want_mask=True)
+        assert np.array_equal(eng.trace(0), otr.astype(capi.ITER_REC_DTYPE))
+        assert np.array_equal(out[0], oout) and np.array_equal(conf[0], oconf)
+        assert np.array_equal(msk[0], omask)
+        it, rem = eng.run()
+        out, conf, msk = eng.download(want_conf=True, want_mask=True)
+        tr = eng.trace(0)
+    assert rem == 0 and not msk.any() and len(tr) == it
+    assert np.array_equal(out[0][m == 0], img[m == 0])
+    assert np.all(np.diff(tr["remaining"]) < 0)
+    assert np.all(conf[0][m == 1] > 0) and np.all(conf[0][m == 1] <= 1)
+    # every source window was free of masked pixels and inside the image
+    assert tr["sy"].min() >= 0 and tr["sx"].min() >= 0
+    assert tr["sy"].max() <= 512 - 9 and tr["sx"].max() <= 512 - 9
