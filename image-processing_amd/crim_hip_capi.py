@@ -64,6 +64,8 @@ def load_library():
     lib.crim_upload.argtypes = [vp, vp, pd, vp, pd]
     lib.crim_upload_batch.restype = ci
     lib.crim_upload_batch.argtypes = [vp, ci, ci, vp, pd, pd, vp, pd, pd]
+    lib.crim_upload_automask.restype = ci
+    lib.crim_upload_automask.argtypes = [vp, ci, ci, vp, pd, pd, ci, ci, ci]
     lib.crim_upload_device.restype = ci
     lib.crim_upload_device.argtypes = [vp, ci, ci, vp, vp]
     lib.crim_run.restype = ci
@@ -159,6 +161,21 @@ class Engine:
         _check(load_library().crim_upload_batch(
             self._h, int(first), n, img.ctypes.data, img.strides[0], img.strides[1],
             msk.ctypes.data, msk.strides[0], msk.strides[1]))
+
+    def upload_automask(self, images, first=0, threshold=10, border_width=10, dilation_size=4):
+        """Uploads images only; the mask is built on the GPU with the recipe of the reference's
+        inpaint_image (src/utils.py:79-100)."""
+        img = np.asarray(images)
+        if img.ndim == 3:
+            img = img[None]
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        n = img.shape[0]
+        if img.shape != (n, self.height, self.width, 3):
+            raise ValueError("upload_automask: expected images [n,%d,%d,3], got %s"
+                             % (self.height, self.width, img.shape))
+        _check(load_library().crim_upload_automask(
+            self._h, int(first), n, img.ctypes.data, img.strides[0], img.strides[1],
+            int(threshold), int(border_width), int(dilation_size)))
 
     def upload_device(self, d_bgr_ptr, d_mask_ptr, first=0, count=None):
         """Dense device buffers (raw pointers as ints) already on this engine's GPU."""

@@ -142,6 +142,19 @@ class Criminisi_Inpainter():
 CriminisiInpainter = Criminisi_Inpainter
 
 
+def inpaint_image(image, patch_size=9, dilation_size=4, device=0):
+    """Mirror of /root/reference/src/utils.py:67-103 (`inpaint_image`): builds the mask of missing
+    (near-black) pixels and inpaints it, with the mask built on the GPU as well."""
+    img = np.asarray(image)
+    if img.ndim != 3 or img.shape[2] != 3 or img.dtype != np.uint8:
+        raise ValueError('image must be a uint8 array of shape (H, W, 3) in BGR order')
+    with capi.Engine(img.shape[0], img.shape[1], patch_size, batch=1, device=device) as eng:
+        eng.upload_automask(img, dilation_size=dilation_size)
+        eng.run()
+        out, _, _ = eng.download()
+    return out[0]
+
+
 def inpaint_many(images, masks, patch_size=9, device=0, batch=None):
     """Inpaints a list/array of same-shaped images as lock-step batches on one GPU: the loop of
     /root/reference/scripts/main.py:44-58 around Criminisi_Inpainter(...).inpaint(), without the

@@ -417,6 +417,31 @@ extern "C" int crim_upload_batch(crim_t* h, int first, int count, const uint8_t*
     return CRIM_OK;
 }
 
+extern "C" int crim_upload_automask(crim_t* h, int first, int count, const uint8_t* bgr,
+                                    ptrdiff_t image_stride, ptrdiff_t row_stride, int threshold,
+                                    int border_width, int dilation_size) {
+    if (!h || !bgr) return fail(CRIM_ERR_ARG, "crim_upload_automask: null argument");
+    const Params& p = h->prm;
+    if (first < 0 || count < 1 || first + count > p.B)
+        return fail(CRIM_ERR_ARG, "crim_upload_automask: images [%d,%d) outside batch of %d", first, first + count, p.B);
+    if (row_stride < (ptrdiff_t)p.W * 3) return fail(CRIM_ERR_ARG, "crim_upload_automask: row stride smaller than a row");
+    if (threshold < 0 || threshold > 255 || border_width < 0 || dilation_size < 1 || dilation_size > 64)
+        return fail(CRIM_ERR_ARG, "crim_upload_automask: threshold %d, border %d or dilation %d out of range",
+                    threshold, border_width, dilation_size);
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t HW = (size_t)p.H * p.W;
+    for (int i = 0; i < count; ++i)
+        HIP_TRY(hipMemcpy2DAsync(p.bgr + (size_t)(first + i) * HW * 3, (size_t)p.W * 3,
+                                 bgr + (ptrdiff_t)i * image_stride, (size_t)row_stride,
+                                 (size_t)p.W * 3, p.H, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_build_mask, dim3(p.tnx, p.tny, count), dim3(256), 0, h->stream, p, first,
+                       threshold, border_width, dilation_size);
+    const int rc = init_images(h, first, count);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return CRIM_OK;
+}
+
 extern "C" int crim_upload(crim_t* h, const uint8_t* bgr, ptrdiff_t row_stride, const uint8_t* mask,
                            ptrdiff_t mask_row_stride) {
     return crim_upload_batch(h, 0, 1, bgr, 0, row_stride, mask, 0, mask_row_stride);

@@ -258,6 +258,31 @@ __device__ __forceinline__ void lab_planes(const Params& p, int B_, int G_, int 
 // upload-time kernels
 // ------------------------------------------------------------------------------------------
 
+// Mask recipe of the reference's caller (src/utils.py:79-100) on the device: grey <= threshold
+// (cv2.inRange(grey, 0, 10)), a border_width-pixel frame cleared, one k x k box dilation
+// (cv2.dilate anchors an even box at k/2: offsets -k/2 .. k-1-k/2; pixels beyond the image never
+// win), then {0,1}.  Reads prm.bgr, writes prm.mask.
+__global__ __launch_bounds__(256) void k_build_mask(Params p, int first, int threshold, int border,
+                                                    int k) {
+    const int b = first + blockIdx.z;
+    const int y = blockIdx.y * CRIM_TILE + (threadIdx.x >> 4);
+    const int x = blockIdx.x * CRIM_TILE + (threadIdx.x & 15);
+    if (y >= p.H || x >= p.W) return;
+    const size_t HW = (size_t)p.H * p.W;
+    const uint8_t* img = p.bgr + b * HW * 3;
+    const int a = k / 2;
+    int m = 0;
+    for (int dy = -a; dy < k - a && !m; ++dy)
+        for (int dx = -a; dx < k - a; ++dx) {
+            const int yy = y + dy, xx = x + dx;
+            if (yy < border || yy >= p.H - border || xx < border || xx >= p.W - border) continue;
+            const uint8_t* px = img + ((size_t)yy * p.W + xx) * 3;
+            const int g = (px[0] * 3735 + px[1] * 19235 + px[2] * 9798 + 16384) >> 15;
+            if (g <= threshold) { m = 1; break; }
+        }
+    p.mask[b * HW + (size_t)y * p.W + x] = (uint8_t)m;
+}
+
 // One block per 16x16 tile: normalises the mask to {0,1}, derives confidence, grey and the
 // search planes and counts the masked pixels.
 __global__ __launch_bounds__(256) void k_init_pixels(Params p, int first) {

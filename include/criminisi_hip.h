@@ -77,6 +77,11 @@ int crim_upload(crim_t* h, const uint8_t* bgr, ptrdiff_t row_stride, const uint8
 int crim_upload_batch(crim_t* h, int first, int count, const uint8_t* bgr, ptrdiff_t image_stride,
                       ptrdiff_t row_stride, const uint8_t* mask, ptrdiff_t mask_image_stride,
                       ptrdiff_t mask_row_stride);
+/* Hands over the image only and builds the mask on the GPU with the recipe of the reference's
+ * caller, inpaint_image (src/utils.py:79-100): grey <= threshold (10 there), a border_width (10)
+ * pixel frame cleared, one dilation_size x dilation_size (4) box dilation, then {0,1}. */
+int crim_upload_automask(crim_t* h, int first, int count, const uint8_t* bgr, ptrdiff_t image_stride,
+                         ptrdiff_t row_stride, int threshold, int border_width, int dilation_size);
 /* Same, from dense device buffers ([count][H][W][3] and [count][H][W]) on the engine's GPU. */
 int crim_upload_device(crim_t* h, int first, int count, const void* d_bgr, const void* d_mask);
 

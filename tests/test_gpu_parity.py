@@ -323,3 +323,25 @@ def test_512_prefix_and_properties():
     # every source window was free of masked pixels and inside the image
     assert tr["sy"].min() >= 0 and tr["sx"].min() >= 0
     assert tr["sy"].max() <= 512 - 9 and tr["sx"].max() <= 512 - 9
+
+
+def test_device_mask_recipe_and_inpaint_image():
+    """The GPU mask builder against the NumPy restatement of src/utils.py:79-100, and the
+    inpaint_image mirror end to end against the committed fixture of a reference dataset image."""
+    from helpers import pipeline_mask
+    from crim_hip_inpainter import inpaint_image
+    g = load_golden("xray_im001")
+    img = g["image"]
+    for k in (3, 4, 5):
+        with capi.Engine(img.shape[0], img.shape[1], 9) as eng:
+            eng.upload_automask(img, dilation_size=k)
+            _, _, msk = eng.download(want_mask=True)
+        assert np.array_equal(msk[0], pipeline_mask(img, dilation_size=k)), k
+    rng = np.random.default_rng(5)
+    small = rng.integers(0, 40, (50, 61, 3), dtype=np.uint8)
+    with capi.Engine(50, 61, 9) as eng:
+        eng.upload_automask(small, dilation_size=4)
+        _, _, msk = eng.download(want_mask=True)
+    assert np.array_equal(msk[0], pipeline_mask(small, dilation_size=4))
+    assert np.array_equal(g["mask"], pipeline_mask(img, dilation_size=4))
+    assert np.array_equal(inpaint_image(img, patch_size=9, dilation_size=4), g["out"])
