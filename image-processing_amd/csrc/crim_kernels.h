@@ -551,7 +551,21 @@ __global__ __launch_bounds__(256) void k_select(Params p) {
     ImgState* st = p.st + b;
     Desc* d = p.desc + b;
     const int tid = threadIdx.x;
-    if (!st->live) {
+    // Dependent memory round trips dominate this kernel, so the partial list is read up to its
+    // capacity together with the loop state; entries beyond the count are ignored.
+    const PEntry* pl = p.plist + (size_t)b * p.pgrid;
+    constexpr int NSPEC = 2;
+    PEntry spec[NSPEC];
+#pragma unroll
+    for (int k = 0; k < NSPEC; ++k) {
+        const int i = tid + 256 * k;
+        spec[k].prio = -1.0; spec[k].pos = 0x7fffffff;
+        if (i < p.pgrid) spec[k] = pl[i];
+    }
+    const int live = st->live;
+    const unsigned n = st->pcount;
+    const int cur = st->cur;
+    if (!live) {
         if (tid == 0) d->live = 0;
         return;
     }
@@ -566,11 +580,14 @@ __global__ __launch_bounds__(256) void k_select(Params p) {
     __shared__ int s_soff;
     __shared__ int s_rowmask;
 
-    const unsigned n = st->pcount;
-    const PEntry* pl = p.plist + (size_t)b * p.pgrid;
     double bestP = -1.0;
     int bestI = 0x7fffffff;
-    for (unsigned i = tid; i < n; i += 256) {
+#pragma unroll
+    for (int k = 0; k < NSPEC; ++k)
+        if ((unsigned)(tid + 256 * k) < n && better_prio(spec[k].prio, spec[k].pos, bestP, bestI)) {
+            bestP = spec[k].prio; bestI = spec[k].pos;
+        }
+    for (unsigned i = tid + 256 * NSPEC; i < n; i += 256) {
         const PEntry e = pl[i];
         if (better_prio(e.prio, e.pos, bestP, bestI)) { bestP = e.prio; bestI = e.pos; }
     }
@@ -598,18 +615,24 @@ __global__ __launch_bounds__(256) void k_select(Params p) {
     const uint8_t* mask = p.mask + b * HW;
     const uint8_t* planes = p.planes + (size_t)b * 5 * H * p.Wp;
 
+    // the target's updated confidence is fetched alongside the patch
+    double cnew_t = 0.0;
+    if (tid == 0) cnew_t = p.conf[((size_t)b * 2 + (cur ^ 1)) * HW + pos];
     int soff_local = 0;
     for (int e = tid; e < P * P; e += 256) {
         const int i = e / P, j = e - i * P;
         int k = 0, t0 = 0, t1 = 0, t2 = 0;
         if (i < ph && j < pw) {
             const int yy = r0 + i, xx = c0 + j;
-            k = 1 - (int)mask[(size_t)yy * W + xx];
+            // mask and planes are loaded together; the planes are discarded under the mask
+            const int mv = mask[(size_t)yy * W + xx];
+            const size_t o = (size_t)yy * p.Wp + xx;
+            const int v0 = (int8_t)planes[o];
+            const int v1 = (int8_t)planes[(size_t)H * p.Wp + o];
+            const int v2 = (int8_t)planes[(size_t)2 * H * p.Wp + o];
+            k = 1 - mv;
             if (k) {
-                const size_t o = (size_t)yy * p.Wp + xx;
-                t0 = (int8_t)planes[o];
-                t1 = (int8_t)planes[(size_t)H * p.Wp + o];
-                t2 = (int8_t)planes[(size_t)2 * H * p.Wp + o];
+                t0 = v0; t1 = v1; t2 = v2;
                 // sum k*T~^2 - sum k*T^2 with T = T~ + 128
                 soff_local += -256 * (t0 + t1 + t2) - 3 * 16384;
                 atomicOr(&s_rowmask, 1 << i);
@@ -653,7 +676,7 @@ __global__ __launch_bounds__(256) void k_select(Params p) {
         d->ncy = H - ph + 1; d->ncx = W - pw + 1;
         d->soff = s_soff;
         d->rowmask = rowmask;
-        d->cnew = p.conf[((size_t)b * 2 + (st->cur ^ 1)) * HW + pos];
+        d->cnew = cnew_t;
         d->ty = (double)(r0 + r1) / 2.0;
         d->tx = (double)(c0 + c1) / 2.0;
         st->pcount = 0;
@@ -952,10 +975,8 @@ __global__ __launch_bounds__(256) void k_search_generic(Params p) {
 __global__ __launch_bounds__(256) void k_update(Params p) {
     const int b = p.b0 + blockIdx.x;
     ImgState* st = p.st + b;
-    if (!st->live) return;
     const Desc* __restrict__ d = p.desc + b;
     const int tid = threadIdx.x;
-    STAMP(16);
     const int H = p.H, W = p.W, P = p.P;
     const size_t HW = (size_t)H * W;
     constexpr int PM = CRIM_PMAX;
@@ -974,54 +995,37 @@ __global__ __launch_bounds__(256) void k_update(Params p) {
     __shared__ unsigned long long s_rb[MR][2];         // per snapshot row: bit j = pixel j masked
     __shared__ unsigned long long s_rw[MR][2];         // OR of P consecutive rows
 
-    // ---- arg-min over the per-block candidates: lowest cost, lowest row-major index (:264)
-    const unsigned n = st->scount;
+    // The kernel is a chain of dependent memory round trips, so independent loads are issued
+    // together.  Round 1: loop state, descriptor, and the partial arg-min list (read up to its
+    // capacity; entries beyond the count are ignored once the count has arrived).
     const SEntry* sl = p.slist + (size_t)b * p.snx * p.sny;
-    double bc = INFINITY;
-    unsigned bi = 0xffffffffu;
-    for (unsigned i = tid; i < n; i += 256) {
-        const SEntry e = sl[i];
-        if (better_cost(e.cost, e.idx, bc, bi)) { bc = e.cost; bi = e.idx; }
+    const int cap = p.snx * p.sny;
+    constexpr int NSPEC = 4;
+    SEntry spec[NSPEC];
+#pragma unroll
+    for (int k = 0; k < NSPEC; ++k) {
+        const int i = tid + 256 * k;
+        spec[k].cost = INFINITY; spec[k].idx = 0xffffffffu;
+        if (i < cap) spec[k] = sl[i];
     }
-    for (int off = 32; off > 0; off >>= 1) {
-        const double oc = __shfl_down(bc, off);
-        const unsigned oi = __shfl_down(bi, off);
-        if (better_cost(oc, oi, bc, bi)) { bc = oc; bi = oi; }
-    }
-    if ((tid & 63) == 0) { s_c[tid >> 6] = bc; s_i[tid >> 6] = bi; }
-    if (tid == 0) s_filled = 0;
-    if (tid < (PM * PM + 31) / 32) s_fill[tid] = 0;
-    __syncthreads();
-    if (tid == 0) {
-        for (int w = 1; w < 4; ++w)
-            if (better_cost(s_c[w], s_i[w], bc, bi)) { bc = s_c[w]; bi = s_i[w]; }
-        // no admissible window: every cost is +inf and np.argmin returns index 0
-        s_src = (bi == 0xffffffffu) ? 0u : bi;
-        s_cost = bc;
-    }
-    __syncthreads();
-    STAMP(17);
+    const int live = st->live;
+    const unsigned n = st->scount;
+    // loop state is read once, up front: thread 0 rewrites it at the end of this kernel
+    const int cur = st->cur;
     const int ncx = d->ncx;
-    const int sy = (int)(s_src / (unsigned)ncx), sx = (int)(s_src % (unsigned)ncx);
     const int r0 = d->r0, c0 = d->c0, ph = d->ph, pw = d->pw;
+    const double cnew = d->cnew;
+    if (!live) return;
+    STAMP(16);
     uint8_t* mask = p.mask + b * HW;
     uint8_t* bgr = p.bgr + b * HW * 3;
     uint8_t* grey = p.grey + b * HW;
     uint8_t* planes = p.planes + (size_t)b * 5 * H * p.Wp;
     const size_t PS = (size_t)H * p.Wp;
-    // loop state is read once, up front: thread 0 rewrites it at the end of this kernel
-    const int cur = st->cur;
     double* cnxt = p.conf + ((size_t)b * 2 + (cur ^ 1)) * HW;
 
-    // ---- snapshot: source pixels, the mask around the patch, the grey values around it
-    for (int e = tid; e < ph * pw; e += 256) {
-        const int i = e / pw, j = e - i * pw;
-        const size_t s = (size_t)(sy + i) * W + sx + j;
-        const size_t so = (size_t)(sy + i) * p.Wp + sx + j;
-        s_px[e][0] = bgr[3 * s]; s_px[e][1] = bgr[3 * s + 1]; s_px[e][2] = bgr[3 * s + 2];
-        for (int k = 0; k < 5; ++k) s_px[e][3 + k] = planes[k * PS + so];
-        s_px[e][8] = grey[s];
-    }
+    // Round 2 (needs only the descriptor): the mask around the patch, the grey values around it,
+    // and the fresh confidence of the pixels within one pixel of the patch.
     const int mg = P - 1 > 2 ? P - 1 : 2;   // margin of the mask snapshot around the patch
     const int mr0 = r0 - mg, mc0 = c0 - mg;
     const int mrh = ph + 2 * mg, mrw = pw + 2 * mg;
@@ -1044,17 +1048,75 @@ __global__ __launch_bounds__(256) void k_update(Params p) {
         }
         s_g[i * GR + j] = v;
     }
+    constexpr int NRF = ((PM + 2) * (PM + 2) + 255) / 256;
+    double rfv[NRF];   // confidence (fresh buffer) of this thread's pixels of the box grown by one
+    {
+        const int ch = ph + 2, cw = pw + 2;
+#pragma unroll
+        for (int k = 0; k < NRF; ++k) {
+            const int e = tid + 256 * k;
+            const int i = e / cw, j = e - i * cw;
+            const int yy = r0 - 1 + i, xx = c0 - 1 + j;
+            rfv[k] = 0.0;
+            if (e < ch * cw && yy >= 0 && yy < H && xx >= 0 && xx < W) rfv[k] = cnxt[(size_t)yy * W + xx];
+        }
+    }
+
+    // ---- arg-min over the per-block candidates: lowest cost, lowest row-major index (:264)
+    double bc = INFINITY;
+    unsigned bi = 0xffffffffu;
+#pragma unroll
+    for (int k = 0; k < NSPEC; ++k)
+        if ((unsigned)(tid + 256 * k) < n && better_cost(spec[k].cost, spec[k].idx, bc, bi)) {
+            bc = spec[k].cost; bi = spec[k].idx;
+        }
+    for (unsigned i = tid + 256 * NSPEC; i < n; i += 256) {
+        const SEntry e = sl[i];
+        if (better_cost(e.cost, e.idx, bc, bi)) { bc = e.cost; bi = e.idx; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double oc = __shfl_down(bc, off);
+        const unsigned oi = __shfl_down(bi, off);
+        if (better_cost(oc, oi, bc, bi)) { bc = oc; bi = oi; }
+    }
+    if ((tid & 63) == 0) { s_c[tid >> 6] = bc; s_i[tid >> 6] = bi; }
+    if (tid == 0) s_filled = 0;
+    if (tid < (PM * PM + 31) / 32) s_fill[tid] = 0;
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (better_cost(s_c[w], s_i[w], bc, bi)) { bc = s_c[w]; bi = s_i[w]; }
+        // no admissible window: every cost is +inf and np.argmin returns index 0
+        s_src = (bi == 0xffffffffu) ? 0u : bi;
+        s_cost = bc;
+    }
+    __syncthreads();
+    STAMP(17);
+    const int sy = (int)(s_src / (unsigned)ncx), sx = (int)(s_src % (unsigned)ncx);
+
+    // Round 3 (needs the source position): the source pixels.
+    for (int e = tid; e < ph * pw; e += 256) {
+        const int i = e / pw, j = e - i * pw;
+        const size_t s = (size_t)(sy + i) * W + sx + j;
+        const size_t so = (size_t)(sy + i) * p.Wp + sx + j;
+        uint8_t v[9];
+        v[0] = bgr[3 * s]; v[1] = bgr[3 * s + 1]; v[2] = bgr[3 * s + 2];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) v[3 + k] = planes[k * PS + so];
+        v[8] = grey[s];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) s_px[e][k] = v[k];
+    }
     __syncthreads();
     STAMP(18);
 
     // ---- fill the masked pixels of the target patch (:274-308)
-    const double cnew = d->cnew;
     int filled = 0;
     for (int e = tid; e < ph * pw; e += 256) {
         const int i = e / pw, j = e - i * pw;
         const int yy = r0 + i, xx = c0 + j;
         const size_t q = (size_t)yy * W + xx;
-        if (mask[q]) {
+        if (s_m0[(i + mg) * MR + (j + mg)]) {
             bgr[3 * q] = s_px[e][0]; bgr[3 * q + 1] = s_px[e][1]; bgr[3 * q + 2] = s_px[e][2];
             const size_t qo = (size_t)yy * p.Wp + xx;
             for (int k = 0; k < 5; ++k) planes[k * PS + qo] = s_px[e][3 + k];
@@ -1146,18 +1208,19 @@ __global__ __launch_bounds__(256) void k_update(Params p) {
     {
         double* cold = p.conf + ((size_t)b * 2 + cur) * HW;
         const int ch = ph + 2, cw = pw + 2;
-        for (int e = tid; e < ch * cw; e += 256) {
+#pragma unroll
+        for (int k = 0; k < NRF; ++k) {
+            const int e = tid + 256 * k;
+            if (e >= ch * cw) continue;
             const int i = e / cw, j = e - i * cw;
             const int yy = r0 - 1 + i, xx = c0 - 1 + j;
             if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
             const size_t q = (size_t)yy * W + xx;
-            double v;
+            double v = rfv[k];
             const int pi = i - 1, pj = j - 1;
             if (pi >= 0 && pi < ph && pj >= 0 && pj < pw &&
                 (s_fill[(pi * pw + pj) >> 5] & (1u << ((pi * pw + pj) & 31))))
                 v = cnew;
-            else
-                v = cnxt[q];
             cold[q] = v;
         }
     }
