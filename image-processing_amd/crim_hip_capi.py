@@ -68,6 +68,12 @@ def load_library():
     lib.crim_upload_automask.argtypes = [vp, ci, ci, vp, pd, pd, ci, ci, ci]
     lib.crim_upload_device.restype = ci
     lib.crim_upload_device.argtypes = [vp, ci, ci, vp, vp]
+    lib.crim_split_virtual.restype = ci
+    lib.crim_split_virtual.argtypes = [vp, ci]
+    lib.crim_split_unique_id.restype = ci
+    lib.crim_split_unique_id.argtypes = [vp]
+    lib.crim_split_init.restype = ci
+    lib.crim_split_init.argtypes = [vp, ci, ci, vp]
     lib.crim_run.restype = ci
     lib.crim_run.argtypes = [vp, cl, ctypes.POINTER(cl), ctypes.POINTER(cl)]
     lib.crim_download.restype = ci
@@ -99,6 +105,13 @@ def _check(rc):
 
 def device_count():
     return int(load_library().crim_device_count())
+
+
+def split_unique_id():
+    """128-byte RCCL id (call on rank 0, share with the other ranks)."""
+    buf = ctypes.create_string_buffer(128)
+    _check(load_library().crim_split_unique_id(buf))
+    return buf.raw
 
 
 def lab_tables():
@@ -183,6 +196,14 @@ class Engine:
         _check(load_library().crim_upload_device(self._h, int(first), int(count),
                                                  ctypes.c_void_p(int(d_bgr_ptr)),
                                                  ctypes.c_void_p(int(d_mask_ptr))))
+
+    # -- split search (one large image) -------------------------------------------------------
+    def split_virtual(self, nparts):
+        _check(load_library().crim_split_virtual(self._h, int(nparts)))
+
+    def split_init(self, nranks, rank, unique_id):
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+        _check(load_library().crim_split_init(self._h, int(nranks), int(rank), buf))
 
     # -- loop -------------------------------------------------------------------------------
     def run(self, max_iters=0):

@@ -2,6 +2,8 @@
 // and the C ABI declared in include/criminisi_hip.h.  Replaces the Python driver loop of
 // Criminisi_Inpainter.inpaint() (/root/reference/src/criminisi_inpainter.py:40-88).
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -164,7 +166,40 @@ struct crim_engine {
     double prof_ms = 0.0, prof_evals = 0.0;
     long prof_launches = 0;
     void* d_peek = nullptr;         // scratch for crim_peek_fields
+    // split search (one image, window-origin rows divided into parts)
+    int split_parts = 0;            // 0: off
+    int split_rank = -1;            // >= 0: this process scores part `rank`, RCCL exchanges the bests
+    ncclComm_t comm = nullptr;
 };
+
+// RCCL is loaded on demand so that the library has no link-time dependency on it.
+namespace {
+struct RcclApi {
+    void* lib = nullptr;
+    decltype(&ncclGetUniqueId) get_unique_id = nullptr;
+    decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+    decltype(&ncclAllGather) all_gather = nullptr;
+    decltype(&ncclCommDestroy) comm_destroy = nullptr;
+    decltype(&ncclGetErrorString) error_string = nullptr;
+};
+RcclApi g_rccl;
+int load_rccl() {
+    if (g_rccl.lib) return CRIM_OK;
+    void* lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) return fail(CRIM_ERR_STATE, "split search: cannot load librccl.so: %s", dlerror());
+    g_rccl.get_unique_id = (decltype(&ncclGetUniqueId))dlsym(lib, "ncclGetUniqueId");
+    g_rccl.comm_init_rank = (decltype(&ncclCommInitRank))dlsym(lib, "ncclCommInitRank");
+    g_rccl.all_gather = (decltype(&ncclAllGather))dlsym(lib, "ncclAllGather");
+    g_rccl.comm_destroy = (decltype(&ncclCommDestroy))dlsym(lib, "ncclCommDestroy");
+    g_rccl.error_string = (decltype(&ncclGetErrorString))dlsym(lib, "ncclGetErrorString");
+    if (!g_rccl.get_unique_id || !g_rccl.comm_init_rank || !g_rccl.all_gather || !g_rccl.comm_destroy)
+        return fail(CRIM_ERR_STATE, "split search: librccl.so lacks a required symbol");
+    g_rccl.lib = lib;
+    return CRIM_OK;
+}
+}  // namespace
 
 static void free_graphs(crim_engine* h) {
     for (auto& ln : h->lanes) {
@@ -174,8 +209,13 @@ static void free_graphs(crim_engine* h) {
     }
 }
 
-static void launch_search(const Params& p, hipStream_t s) {
-    dim3 grid(p.snx, p.sny, p.B), block(256);
+// Search over block rows [sy0, sy0 + rows) of the window-origin grid (all rows when rows < 0).
+static void launch_search(const Params& pin, hipStream_t s, int sy0 = 0, int rows = -1) {
+    Params p = pin;
+    p.sy0 = sy0;
+    if (rows < 0) rows = p.sny;
+    if (rows == 0) return;
+    dim3 grid(p.snx, rows, p.B), block(256);
     if (p.generic) {
         hipLaunchKernelGGL(k_search_generic, grid, block, 0, s, p);
         return;
@@ -258,12 +298,13 @@ extern "C" void crim_destroy(crim_t* h) {
     for (auto& ln : h->lanes)
         if (ln.stream) (void)hipStreamSynchronize(ln.stream);
     free_graphs(h);
+    if (h->comm && g_rccl.comm_destroy) (void)g_rccl.comm_destroy(h->comm);
     for (auto& ln : h->lanes)
         if (ln.stream) (void)hipStreamDestroy(ln.stream);
     for (auto e : h->ev) (void)hipEventDestroy(e);
     Params& p = h->prm;
     void* bufs[] = {p.bgr, p.planes, p.mask, p.grey, p.grad, p.conf, p.invalid, p.tfront, p.tlist, p.st,
-                    p.desc, p.plist, p.slist, p.trace, p.dbg, h->d_gamma, h->d_cbrt, h->d_peek};
+                    p.desc, p.plist, p.slist, p.xchg, p.trace, p.dbg, h->d_gamma, h->d_cbrt, h->d_peek};
     for (void* q : bufs)
         if (q) (void)hipFree(q);
     if (h->h_state) (void)hipHostFree(h->h_state);
@@ -329,6 +370,7 @@ extern "C" int crim_create_batch(int batch, int H, int W, int patch_size, int de
     alloc((void**)&p.plist, Bz * p.pgrid * sizeof(PEntry));
     alloc((void**)&p.slist, Bz * p.snx * p.sny * sizeof(SEntry));
     alloc((void**)&p.dbg, 64 * sizeof(long long));
+    alloc((void**)&p.xchg, 64 * sizeof(SEntry));
     alloc((void**)&h->d_gamma, sizeof(t.gamma));
     alloc((void**)&h->d_cbrt, sizeof(t.cbrt_));
     if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_state, Bz * sizeof(ImgState), hipHostMallocDefault);
@@ -517,6 +559,92 @@ static int flush_profile(crim_engine* h) {
     return CRIM_OK;
 }
 
+// Fill loop with the search split into parts (one image).  Launched eagerly: every iteration is
+// priority, select, the search of this process's part(s) each folded into its exchange slot, the
+// RCCL all-gather of the 16-byte slots when the parts live in different processes, update.
+static int run_split(crim_engine* h, long max_iters) {
+    Lane& ln = h->lanes[0];
+    Params p = ln.prm;
+    p.nparts = h->split_parts;
+    const int parts = h->split_parts;
+    long done = 0;
+    for (;;) {
+        HIP_TRY(hipMemcpyAsync(h->h_state, p.st, sizeof(ImgState), hipMemcpyDeviceToHost, ln.stream));
+        HIP_TRY(hipStreamSynchronize(ln.stream));
+        const ImgState& s = h->h_state[0];
+        if (s.stalled || !s.live) break;
+        long need = std::max(1L, ((long)s.remaining + p.P * p.P - 1) / (p.P * p.P));
+        need = std::min(need, 64L);
+        if (max_iters > 0) need = std::min(need, max_iters - done);
+        if (need <= 0) break;
+        for (long it = 0; it < need; ++it) {
+            if ((done + it) > 0 && (done + it) % COMPACT_PERIOD == 0) launch_compact(p, ln.stream);
+            hipLaunchKernelGGL(k_priority, dim3(p.pgrid, p.B), dim3(64), priority_lds_bytes(p), ln.stream, p);
+            hipLaunchKernelGGL(k_select, dim3(p.B), dim3(256), 0, ln.stream, p);
+            for (int part = 0; part < parts; ++part) {
+                if (h->split_rank >= 0 && part != h->split_rank) continue;
+                const int y0 = (int)((long)p.sny * part / parts), y1 = (int)((long)p.sny * (part + 1) / parts);
+                launch_search(p, ln.stream, y0, y1 - y0);
+                hipLaunchKernelGGL(k_local_best, dim3(1), dim3(256), 0, ln.stream, p, part);
+            }
+            if (h->split_rank >= 0) {
+                const ncclResult_t r = g_rccl.all_gather(p.xchg + h->split_rank, p.xchg, sizeof(SEntry),
+                                                         ncclInt8, h->comm, ln.stream);
+                if (r != ncclSuccess)
+                    return fail(CRIM_ERR_HIP, "ncclAllGather: %s", g_rccl.error_string ? g_rccl.error_string(r) : "error");
+            }
+            hipLaunchKernelGGL(k_update, dim3(p.B), dim3(256), 0, ln.stream, p);
+        }
+        done += need;
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipMemcpyAsync(h->h_state, p.st, sizeof(ImgState), hipMemcpyDeviceToHost, ln.stream));
+    HIP_TRY(hipStreamSynchronize(ln.stream));
+    return CRIM_OK;
+}
+
+extern "C" int crim_split_unique_id(void* out128) {
+    if (!out128) return fail(CRIM_ERR_ARG, "crim_split_unique_id: null argument");
+    const int rc = load_rccl();
+    if (rc) return rc;
+    ncclUniqueId id;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    const ncclResult_t r = g_rccl.get_unique_id(&id);
+    if (r != ncclSuccess) return fail(CRIM_ERR_HIP, "ncclGetUniqueId failed (%d)", (int)r);
+    memcpy(out128, &id, sizeof(id));
+    return CRIM_OK;
+}
+
+extern "C" int crim_split_init(crim_t* h, int nranks, int rank, const void* unique_id128) {
+    if (!h || !unique_id128) return fail(CRIM_ERR_ARG, "crim_split_init: null argument");
+    if (h->prm.B != 1) return fail(CRIM_ERR_ARG, "crim_split_init: the split search handles one image per engine");
+    if (nranks < 1 || nranks > 64 || rank < 0 || rank >= nranks)
+        return fail(CRIM_ERR_ARG, "crim_split_init: rank %d of %d", rank, nranks);
+    const int rc = load_rccl();
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(h->device));
+    ncclUniqueId id;
+    memcpy(&id, unique_id128, sizeof(id));
+    if (h->comm) { (void)g_rccl.comm_destroy(h->comm); h->comm = nullptr; }
+    HIP_TRY(hipDeviceSynchronize());
+    (void)hipGetLastError();   // RCCL treats a stale error left by an earlier, unrelated call as its own
+    const ncclResult_t r = g_rccl.comm_init_rank(&h->comm, nranks, id, rank);
+    if (r != ncclSuccess)
+        return fail(CRIM_ERR_HIP, "ncclCommInitRank: %s", g_rccl.error_string ? g_rccl.error_string(r) : "error");
+    h->split_parts = nranks;
+    h->split_rank = rank;
+    return CRIM_OK;
+}
+
+extern "C" int crim_split_virtual(crim_t* h, int nparts) {
+    if (!h) return fail(CRIM_ERR_ARG, "crim_split_virtual: null handle");
+    if (h->prm.B != 1) return fail(CRIM_ERR_ARG, "crim_split_virtual: the split search handles one image per engine");
+    if (nparts < 0 || nparts > 64) return fail(CRIM_ERR_ARG, "crim_split_virtual: %d parts", nparts);
+    h->split_parts = nparts;
+    h->split_rank = -1;
+    return CRIM_OK;
+}
+
 extern "C" int crim_run(crim_t* h, long max_iters, long* iters_done, long* remaining) {
     if (!h) return fail(CRIM_ERR_ARG, "crim_run: null handle");
     HIP_TRY(hipSetDevice(h->device));
@@ -529,7 +657,12 @@ extern "C" int crim_run(crim_t* h, long max_iters, long* iters_done, long* remai
     const bool eager = (h->flags & CRIM_FLAG_EAGER) != 0;
     for (auto& ln : h->lanes) ln.done = 0;
     int rc = CRIM_OK;
-    for (;;) {
+    if (h->split_parts > 0) {
+        const int r2 = run_split(h, max_iters);
+        if (r2) return r2;
+        if (h->h_state[0].stalled) rc = CRIM_ERR_NO_PROGRESS;
+    }
+    for (; h->split_parts == 0;) {
         // every lane is idle here
         HIP_TRY(hipMemcpyAsync(h->h_state, p.st, (size_t)p.B * sizeof(ImgState), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));

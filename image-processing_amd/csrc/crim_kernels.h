@@ -757,7 +757,7 @@ __global__ __launch_bounds__(256) void k_search(Params p) {
     const Desc* __restrict__ d = p.desc + b;
     if (!d->live) return;
     const int ncy = d->ncy, ncx = d->ncx;
-    const int y0 = blockIdx.y * SB_H, x0 = blockIdx.x * SB_W;
+    const int y0 = (p.sy0 + blockIdx.y) * SB_H, x0 = blockIdx.x * SB_W;
     if (y0 >= ncy || x0 >= ncx) return;
     const int tid = threadIdx.x, tx = tid & (SB_TXG - 1), ty = tid / SB_TXG;
     if (tid == 0) s_bound = __hip_atomic_load(&p.st[b].bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -931,7 +931,7 @@ __global__ __launch_bounds__(256) void k_search_generic(Params p) {
     const Desc* __restrict__ d = p.desc + b;
     if (!d->live) return;
     const int ncy = d->ncy, ncx = d->ncx;
-    const int y0 = blockIdx.y * SB_H, x0 = blockIdx.x * SB_W;
+    const int y0 = (p.sy0 + blockIdx.y) * SB_H, x0 = blockIdx.x * SB_W;
     if (y0 >= ncy || x0 >= ncx) return;
     const int tid = threadIdx.x;
     const int H = p.H, W = p.W, P = p.P;
@@ -968,6 +968,42 @@ __global__ __launch_bounds__(256) void k_search_generic(Params p) {
     block_min_emit(p, b, bc, bi, s_c, s_i);
 }
 
+// Split search (one image, the window-origin rows divided into parts that different launches --
+// on one GPU or on several -- score): folds the partial list of the part just searched into
+// slot `part` of the exchange array and empties the list for the next part.  Every process then
+// holds all slots (directly, or after an all-gather) and k_update reduces them.
+__global__ __launch_bounds__(256) void k_local_best(Params p, int part) {
+    const int b = p.b0;
+    ImgState* st = p.st + b;
+    if (!st->live) return;
+    __shared__ double s_c[4];
+    __shared__ unsigned s_i[4];
+    const int tid = threadIdx.x;
+    const unsigned n = st->scount;
+    const SEntry* sl = p.slist + (size_t)b * p.snx * p.sny;
+    double bc = INFINITY;
+    unsigned bi = 0xffffffffu;
+    for (unsigned i = tid; i < n; i += 256) {
+        const SEntry e = sl[i];
+        if (better_cost(e.cost, e.idx, bc, bi)) { bc = e.cost; bi = e.idx; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double oc = __shfl_down(bc, off);
+        const unsigned oi = __shfl_down(bi, off);
+        if (better_cost(oc, oi, bc, bi)) { bc = oc; bi = oi; }
+    }
+    if ((tid & 63) == 0) { s_c[tid >> 6] = bc; s_i[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (better_cost(s_c[w], s_i[w], bc, bi)) { bc = s_c[w]; bi = s_i[w]; }
+        SEntry e;
+        e.cost = bc; e.idx = bi; e.pad = 0;
+        p.xchg[part] = e;
+        st->scount = 0;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // iteration kernel 4: pick the source, copy the patch, maintain every cached field
 // ------------------------------------------------------------------------------------------
@@ -998,8 +1034,8 @@ __global__ __launch_bounds__(256) void k_update(Params p) {
     // The kernel is a chain of dependent memory round trips, so independent loads are issued
     // together.  Round 1: loop state, descriptor, and the partial arg-min list (read up to its
     // capacity; entries beyond the count are ignored once the count has arrived).
-    const SEntry* sl = p.slist + (size_t)b * p.snx * p.sny;
-    const int cap = p.snx * p.sny;
+    const SEntry* sl = p.nparts > 0 ? p.xchg : p.slist + (size_t)b * p.snx * p.sny;
+    const int cap = p.nparts > 0 ? p.nparts : p.snx * p.sny;
     constexpr int NSPEC = 4;
     SEntry spec[NSPEC];
 #pragma unroll
@@ -1009,7 +1045,7 @@ __global__ __launch_bounds__(256) void k_update(Params p) {
         if (i < cap) spec[k] = sl[i];
     }
     const int live = st->live;
-    const unsigned n = st->scount;
+    const unsigned n = p.nparts > 0 ? (unsigned)p.nparts : st->scount;
     // loop state is read once, up front: thread 0 rewrites it at the end of this kernel
     const int cur = st->cur;
     const int ncx = d->ncx;

@@ -75,6 +75,8 @@ struct Params {
     int Wi;       // pitch of the window-validity map
     int tnx, tny; // 16x16 tile grid over the whole image (upload-time kernels)
     int snx, sny; // search block grid
+    int sy0;      // first block row a search launch covers (split search; 0 otherwise)
+    int nparts;   // > 0: split search, k_update reduces xchg[0..nparts) instead of the partial list
     int pgrid;    // priority-scan blocks per image
     int generic;  // use the unspecialised search kernel
     long trace_cap;
@@ -92,6 +94,7 @@ struct Params {
     int* tlist;        // [B][tcap] tiles the priority stage visits
     PEntry* plist;     // [B][pgrid]
     SEntry* slist;     // [B][snx*sny]
+    SEntry* xchg;      // [64] per-part best window of a split search
     crim_iter_rec* trace;  // [B][trace_cap]
     long long* dbg;        // diagnostic stamps (only written by -DCRIM_STAMPS builds)
     const uint16_t* gamma_tab;

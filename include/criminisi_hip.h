@@ -90,6 +90,20 @@ int crim_upload_device(crim_t* h, int first, int count, const void* d_bgr, const
  * the largest per-image iteration count so far, remaining the total masked pixels left. */
 int crim_run(crim_t* h, long max_iters, long* iters_done, long* remaining);
 
+/* Split search for ONE large image (batch 1): the rows of window origins scored by
+ * _find_source_patch (:240-264) are divided into parts; each part's best window is a 16-byte
+ * (cost, index) record and the lexicographic minimum over the parts is the reference's arg-min.
+ * No counterpart in the reference (it is single-process).
+ *   crim_split_virtual: the parts are scored one after another by this engine (checks the
+ *     partitioning on one GPU; nparts 0 switches the split off).
+ *   crim_split_init: this process scores part `rank` of `nranks`; every process holds a replica
+ *     of the image state and the records are exchanged by one RCCL all-gather per iteration.
+ *     unique_id128 is the 128-byte id rank 0 obtained from crim_split_unique_id and shared out of
+ *     band (e.g. torch.distributed broadcast). */
+int crim_split_virtual(crim_t* h, int nparts);
+int crim_split_unique_id(void* out128);
+int crim_split_init(crim_t* h, int nranks, int rank, const void* unique_id128);
+
 /* working_image (:88), confidence and working_mask after the run; null outputs are skipped. */
 int crim_download(crim_t* h, uint8_t* bgr_out, double* conf_out, uint8_t* mask_out);
 int crim_download_batch(crim_t* h, int first, int count, uint8_t* bgr_out, double* conf_out,

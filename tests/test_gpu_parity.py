@@ -345,3 +345,57 @@ def test_device_mask_recipe_and_inpaint_image():
     assert np.array_equal(msk[0], pipeline_mask(small, dilation_size=4))
     assert np.array_equal(g["mask"], pipeline_mask(img, dilation_size=4))
     assert np.array_equal(inpaint_image(img, patch_size=9, dilation_size=4), g["out"])
+
+
+@pytest.mark.parametrize("nparts", [2, 3, 8])
+def test_split_search_virtual_parts(nparts):
+    """The window-origin rows divided into parts, each part reduced to one (cost, index) record:
+    the result must equal the unsplit search (and the oracle) bit for bit."""
+    img = crim_synth.xray_like(160, 144, 1200 + nparts, colour=True)
+    m = crim_synth.blob_mask(160, 144, 1200 + nparts, fraction=0.08, margin=9)
+    m[0:5, 0:7] = 1      # a border-clipped patch on the way
+    oout, oconf, _, otr, n = c_oracle.run(img, m, 9)
+    with capi.Engine(160, 144, 9) as eng:
+        eng.split_virtual(nparts)
+        eng.upload(img, m)
+        eng.run()
+        out, conf, _ = eng.download(want_conf=True)
+        tr = eng.trace(0)
+    assert np.array_equal(tr, otr.astype(capi.ITER_REC_DTYPE))
+    assert np.array_equal(out[0], oout) and np.array_equal(conf[0], oconf)
+
+
+_RCCL_SCRIPT = r"""
+import sys
+sys.path[:0] = [%r, %r]
+import numpy as np
+import crim_hip_capi as capi, crim_synth
+from oracle import c_oracle
+img = crim_synth.xray_like(96, 96, 1300, colour=True)
+m = crim_synth.blob_mask(96, 96, 1300, fraction=0.06, margin=9)
+oout, oconf, _, otr, n = c_oracle.run(img, m, 9)
+uid = capi.split_unique_id()
+assert len(uid) == 128
+with capi.Engine(96, 96, 9) as eng:
+    eng.split_init(1, 0, uid)
+    eng.upload(img, m)
+    eng.run()
+    out, conf, _ = eng.download(want_conf=True)
+    tr = eng.trace(0)
+assert np.array_equal(tr, otr.astype(capi.ITER_REC_DTYPE))
+assert np.array_equal(out[0], oout) and np.array_equal(conf[0], oconf)
+print("RCCL_SINGLE_RANK_OK", n)
+"""
+
+
+def test_split_search_rccl_single_rank():
+    """The RCCL transport with a communicator of one rank (all this box can host): the in-place
+    all-gather of the 16-byte records runs every iteration and the result stays exact.  Runs in
+    a process of its own: RCCL must find the same ROCm runtime the engine uses, which a process
+    that has also imported PyTorch's bundled copy does not guarantee."""
+    import subprocess
+    import sys
+    from helpers import ROOT, PKG
+    r = subprocess.run([sys.executable, "-c", _RCCL_SCRIPT % (ROOT, PKG)], capture_output=True,
+                       text=True, timeout=240)
+    assert r.returncode == 0 and "RCCL_SINGLE_RANK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
