@@ -579,6 +579,7 @@ __global__ __launch_bounds__(256) void k_select(Params p) {
     __shared__ int8_t s_t[3][CRIM_PMAX * CRIM_PMAX];
     __shared__ int s_soff;
     __shared__ int s_rowmask;
+    __shared__ int s_chmask;
 
     double bestP = -1.0;
     int bestI = 0x7fffffff;
@@ -597,7 +598,7 @@ __global__ __launch_bounds__(256) void k_select(Params p) {
         if (better_prio(op, oi, bestP, bestI)) { bestP = op; bestI = oi; }
     }
     if ((tid & 63) == 0) { s_bp[tid >> 6] = bestP; s_bi[tid >> 6] = bestI; }
-    if (tid == 0) { s_soff = 0; s_rowmask = 0; }
+    if (tid == 0) { s_soff = 0; s_rowmask = 0; s_chmask = 0; }
     __syncthreads();
     if (tid == 0) {
         for (int w = 1; w < 4; ++w)
@@ -636,6 +637,8 @@ __global__ __launch_bounds__(256) void k_select(Params p) {
                 // sum k*T~^2 - sum k*T^2 with T = T~ + 128
                 soff_local += -256 * (t0 + t1 + t2) - 3 * 16384;
                 atomicOr(&s_rowmask, 1 << i);
+                const int cm = (t0 ? 1 : 0) | (t1 ? 2 : 0) | (t2 ? 4 : 0);
+                if (cm) atomicOr(&s_chmask, cm);
             }
         }
         s_k[e] = (uint8_t)k;
@@ -676,6 +679,7 @@ __global__ __launch_bounds__(256) void k_select(Params p) {
         d->ncy = H - ph + 1; d->ncx = W - pw + 1;
         d->soff = s_soff;
         d->rowmask = rowmask;
+        d->chmask = s_chmask;
         d->cnew = cnew_t;
         d->ty = (double)(r0 + r1) / 2.0;
         d->tx = (double)(c0 + c1) / 2.0;
@@ -792,7 +796,10 @@ __global__ __launch_bounds__(256) void k_search(Params p) {
     // 57 us vs 56 us per launch of 128 images with a 10 % mask.)
     if (!__syncthreads_or(vbits != 0)) return;
 
-    // stage the five byte planes of this tile (zero beyond the image): 16-byte chunks, all of a
+    // A Lab channel whose template k*(T-128) is zero everywhere adds nothing to the cross term
+    // (a and b of every grey pixel are exactly 128), so its plane is neither staged nor scored.
+    const int chmask = d->chmask | 0x18;
+    // stage the byte planes of this tile (zero beyond the image): 16-byte chunks, all of a
     // thread's loads issued before the first LDS store
     const uint8_t* pl = p.planes + (size_t)b * 5 * H * p.Wp;
     {
@@ -806,7 +813,7 @@ __global__ __launch_bounds__(256) void k_search(Params p) {
             const int row = rem / LC4, c4 = rem - row * LC4;
             const int gy = y0 + row, gx = x0 + 16 * c4;
             v[k] = make_uint4(0, 0, 0, 0);
-            if (c < NCHUNK && gy < H && gx + 16 <= p.Wp)
+            if (c < NCHUNK && gy < H && gx + 16 <= p.Wp && ((chmask >> pln) & 1))
                 v[k] = *(const uint4*)(pl + ((size_t)pln * H + gy) * p.Wp + gx);
         }
 #pragma unroll
@@ -830,6 +837,7 @@ __global__ __launch_bounds__(256) void k_search(Params p) {
         const_u32_ptr tm = as_const_u32(d->tmpl);
 #pragma unroll 1
         for (int ch = 0; ch < 3; ++ch) {
+            if (!((chmask >> ch) & 1)) continue;
             uint32_t img[R + P - 1][ND];
 #pragma unroll
             for (int rr = 0; rr < R + P - 1; ++rr)

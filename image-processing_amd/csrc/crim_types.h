@@ -53,6 +53,8 @@ struct Desc {
     int ncy, ncx;        // candidate grid: H-ph+1, W-pw+1
     int soff;            // S_reference = S_centred + soff
     int rowmask;         // bit i set: template row i has at least one known pixel
+    int chmask;          // bit c set: k * (Lab_c - 128) is nonzero somewhere in the template
+    int pad1;
     double cnew;         // updated confidence at the target pixel
     double ty, tx;       // patch centre as the reference computes it
     // Templates as byte planes, zero padded: kflat = 1 - mask, tflat = k * (Lab - 128).
