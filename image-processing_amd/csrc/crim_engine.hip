@@ -220,6 +220,20 @@ static void launch_search(const Params& pin, hipStream_t s, int sy0 = 0, int row
         hipLaunchKernelGGL(k_search_generic, grid, block, 0, s, p);
         return;
     }
+    if (!p.dot4) {
+        // SB_H == MS_ROWS: the block rows of both specialised kernels coincide
+        dim3 mgrid((std::max(p.W - p.half, 1) + MS_W - 1) / MS_W, rows, p.B);
+        switch (p.P) {
+            case 3: if (p.chroma) hipLaunchKernelGGL((k_search_mfma<3, true>), mgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_mfma<3, false>), mgrid, block, 0, s, p); return;
+            case 5: if (p.chroma) hipLaunchKernelGGL((k_search_mfma<5, true>), mgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_mfma<5, false>), mgrid, block, 0, s, p); return;
+            case 7: if (p.chroma) hipLaunchKernelGGL((k_search_mfma<7, true>), mgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_mfma<7, false>), mgrid, block, 0, s, p); return;
+            case 9: if (p.chroma) hipLaunchKernelGGL((k_search_mfma<9, true>), mgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_mfma<9, false>), mgrid, block, 0, s, p); return;
+            case 11: if (p.chroma) hipLaunchKernelGGL((k_search_mfma<11, true>), mgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_mfma<11, false>), mgrid, block, 0, s, p); return;
+            case 13: if (p.chroma) hipLaunchKernelGGL((k_search_mfma<13, true>), mgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_mfma<13, false>), mgrid, block, 0, s, p); return;
+            case 15: if (p.chroma) hipLaunchKernelGGL((k_search_mfma<15, true>), mgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_mfma<15, false>), mgrid, block, 0, s, p); return;
+            default: break;
+        }
+    }
     switch (p.P) {
         case 3: hipLaunchKernelGGL(k_search<3>, grid, block, 0, s, p); break;
         case 5: hipLaunchKernelGGL(k_search<5>, grid, block, 0, s, p); break;
@@ -345,6 +359,7 @@ extern "C" int crim_create_batch(int batch, int H, int W, int patch_size, int de
     p.snx = (std::max(W - p.half, 1) + SB_W - 1) / SB_W;
     p.sny = (std::max(H - p.half, 1) + SB_H - 1) / SB_H;
     p.generic = ((flags & CRIM_FLAG_GENERIC_SEARCH) || !has_fast_search(p.P)) ? 1 : 0;
+    p.dot4 = (flags & CRIM_FLAG_DOT4_SEARCH) ? 1 : 0;
     p.trace_cap = 0;
     const size_t HW = (size_t)H * W, Bz = (size_t)batch;
     const LabTables& t = lab_tables();
@@ -354,7 +369,7 @@ extern "C" int crim_create_batch(int batch, int H, int W, int patch_size, int de
         if (e == hipSuccess) e = hipMalloc(ptr, bytes);
     };
     alloc((void**)&p.bgr, Bz * HW * 3);
-    alloc((void**)&p.planes, Bz * 5 * H * p.Wp);
+    alloc((void**)&p.planes, Bz * CRIM_NPL * H * p.Wp);
     alloc((void**)&p.mask, Bz * HW);
     alloc((void**)&p.grey, Bz * HW);
     alloc((void**)&p.grad, Bz * HW * sizeof(int));
@@ -377,7 +392,7 @@ extern "C" int crim_create_batch(int batch, int H, int W, int patch_size, int de
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMemcpy(h->d_gamma, t.gamma, sizeof(t.gamma), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(h->d_cbrt, t.cbrt_, sizeof(t.cbrt_), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemset(p.planes, 0, Bz * 5 * H * p.Wp);
+    if (e == hipSuccess) e = hipMemset(p.planes, 0, Bz * CRIM_NPL * H * p.Wp);
     if (e == hipSuccess) e = hipMemset(p.invalid, 1, Bz * H * p.Wi);
     if (e == hipSuccess) e = hipMemset(p.st, 0, Bz * sizeof(ImgState));
     if (e == hipSuccess) e = hipMemset(p.dbg, 0, 64 * sizeof(long long));
@@ -514,6 +529,8 @@ static int prepare(crim_engine* h) {
     Params q = p;
     long need = 1;
     for (int i = 0; i < p.B; ++i) need = std::max(need, (long)h->h_state[i].remaining + 1);
+    q.chroma = 0;
+    for (int i = 0; i < p.B; ++i) q.chroma |= h->h_state[i].chroma ? 1 : 0;
     if (need > p.trace_cap || !p.trace) {
         if (p.trace) HIP_TRY(hipFree(p.trace));
         q.trace = nullptr;

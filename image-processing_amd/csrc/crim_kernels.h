@@ -235,7 +235,7 @@ __device__ __forceinline__ int grad_packed(const uint8_t* grey, const uint8_t* m
 // search planes derived from it: Lab - 128 per channel and Q = sum (Lab-128)^2 split as
 // Q % 255 and Q / 255, so that sum k*Q = dot(Q%255, k) + dot(Q/255, 255*k) stays in byte dot
 // products.
-__device__ __forceinline__ void lab_planes(const Params& p, int B_, int G_, int R_, uint8_t out[5]) {
+__device__ __forceinline__ void lab_planes(const Params& p, int B_, int G_, int R_, uint8_t out[CRIM_NPL]) {
     const int b = p.gamma_tab[B_], g = p.gamma_tab[G_], r = p.gamma_tab[R_];
     const int fX = p.cbrt_tab[(b * p.coef[0] + g * p.coef[1] + r * p.coef[2] + 2048) >> 12];
     const int fY = p.cbrt_tab[(b * p.coef[3] + g * p.coef[4] + r * p.coef[5] + 2048) >> 12];
@@ -252,6 +252,12 @@ __device__ __forceinline__ void lab_planes(const Params& p, int B_, int G_, int 
     out[2] = (uint8_t)(int8_t)bb;
     out[3] = (uint8_t)(Q % 255);
     out[4] = (uint8_t)(Q / 255);
+    // Q <= 3 * 128^2 = 49152; Q - 24576 = 256*h + l with l in [-128,127], h in [-96,96]: both
+    // fit the signed bytes the i8 matrix cores take.
+    const int Qc = Q - 24576;
+    const int h = (Qc + 128) >> 8;
+    out[5] = (uint8_t)(int8_t)(Qc - 256 * h);
+    out[6] = (uint8_t)(int8_t)h;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -290,7 +296,7 @@ __global__ __launch_bounds__(256) void k_init_pixels(Params p, int first) {
     const int y = blockIdx.y * CRIM_TILE + (threadIdx.x >> 4);
     const int x = blockIdx.x * CRIM_TILE + (threadIdx.x & 15);
     const size_t HW = (size_t)p.H * p.W;
-    int m = 0;
+    int m = 0, chroma = 0;
     if (y < p.H && x < p.W) {
         const size_t i = (size_t)y * p.W + x;
         uint8_t* mk = p.mask + b * HW;
@@ -302,13 +308,15 @@ __global__ __launch_bounds__(256) void k_init_pixels(Params p, int first) {
         const uint8_t* px = p.bgr + (b * HW + i) * 3;
         const int B_ = px[0], G_ = px[1], R_ = px[2];
         p.grey[b * HW + i] = (uint8_t)((B_ * 3735 + G_ * 19235 + R_ * 9798 + 16384) >> 15);
-        uint8_t pl[5];
+        uint8_t pl[CRIM_NPL];
         lab_planes(p, B_, G_, R_, pl);
-        uint8_t* base = p.planes + (size_t)b * 5 * p.H * p.Wp + (size_t)y * p.Wp + x;
-        for (int k = 0; k < 5; ++k) base[(size_t)k * p.H * p.Wp] = pl[k];
+        uint8_t* base = p.planes + (size_t)b * CRIM_NPL * p.H * p.Wp + (size_t)y * p.Wp + x;
+        for (int k = 0; k < CRIM_NPL; ++k) base[(size_t)k * p.H * p.Wp] = pl[k];
+        chroma = (pl[1] | pl[2]) ? 1 : 0;
     }
     const int cnt = __syncthreads_count(m);
     if (threadIdx.x == 0 && cnt) atomicAdd(&p.st[b].remaining, cnt);
+    if (__syncthreads_or(chroma) && threadIdx.x == 0) atomicOr(&p.st[b].chroma, 1);
 }
 
 // Gradient field, window-validity map and the per-tile count of front pixels; needs the
@@ -346,7 +354,7 @@ __global__ void k_init_state(Params p, int first, int count) {
     if (i >= count) return;
     ImgState* s = p.st + first + i;
     s->iter = 0; s->live = 1; s->cur = 0; s->remaining = 0;
-    s->tcount = 0;
+    s->tcount = 0; s->chroma = 0;
     s->pcount = 0; s->scount = 0; s->stalled = 0; s->bound = 0x7fffffff;
     p.desc[first + i].live = 0;
 }
@@ -580,6 +588,7 @@ __global__ __launch_bounds__(256) void k_select(Params p) {
     __shared__ int s_soff;
     __shared__ int s_rowmask;
     __shared__ int s_chmask;
+    __shared__ int s_nk;
 
     double bestP = -1.0;
     int bestI = 0x7fffffff;
@@ -598,7 +607,7 @@ __global__ __launch_bounds__(256) void k_select(Params p) {
         if (better_prio(op, oi, bestP, bestI)) { bestP = op; bestI = oi; }
     }
     if ((tid & 63) == 0) { s_bp[tid >> 6] = bestP; s_bi[tid >> 6] = bestI; }
-    if (tid == 0) { s_soff = 0; s_rowmask = 0; s_chmask = 0; }
+    if (tid == 0) { s_soff = 0; s_rowmask = 0; s_chmask = 0; s_nk = 0; }
     __syncthreads();
     if (tid == 0) {
         for (int w = 1; w < 4; ++w)
@@ -614,12 +623,12 @@ __global__ __launch_bounds__(256) void k_select(Params p) {
     const int c0 = imax(0, tc - p.half), c1 = imin(tc + p.half, W - 1);
     const int ph = r1 - r0 + 1, pw = c1 - c0 + 1;
     const uint8_t* mask = p.mask + b * HW;
-    const uint8_t* planes = p.planes + (size_t)b * 5 * H * p.Wp;
+    const uint8_t* planes = p.planes + (size_t)b * CRIM_NPL * H * p.Wp;
 
     // the target's updated confidence is fetched alongside the patch
     double cnew_t = 0.0;
     if (tid == 0) cnew_t = p.conf[((size_t)b * 2 + (cur ^ 1)) * HW + pos];
-    int soff_local = 0;
+    int soff_local = 0, nk_local = 0;
     for (int e = tid; e < P * P; e += 256) {
         const int i = e / P, j = e - i * P;
         int k = 0, t0 = 0, t1 = 0, t2 = 0;
@@ -636,6 +645,7 @@ __global__ __launch_bounds__(256) void k_select(Params p) {
                 t0 = v0; t1 = v1; t2 = v2;
                 // sum k*T~^2 - sum k*T^2 with T = T~ + 128
                 soff_local += -256 * (t0 + t1 + t2) - 3 * 16384;
+                ++nk_local;
                 atomicOr(&s_rowmask, 1 << i);
                 const int cm = (t0 ? 1 : 0) | (t1 ? 2 : 0) | (t2 ? 4 : 0);
                 if (cm) atomicOr(&s_chmask, cm);
@@ -647,6 +657,7 @@ __global__ __launch_bounds__(256) void k_select(Params p) {
         d->tflat[0][e] = (int8_t)t0; d->tflat[1][e] = (int8_t)t1; d->tflat[2][e] = (int8_t)t2;
     }
     if (soff_local) atomicAdd(&s_soff, soff_local);
+    if (nk_local) atomicAdd(&s_nk, nk_local);
     __syncthreads();
     STAMP(10);
 
@@ -671,6 +682,47 @@ __global__ __launch_bounds__(256) void k_select(Params p) {
         }
         d->tmpl[e] = v;
     }
+    // operand fragments of the matrix-core search (layout: Desc::tmplB): a lane's 16 bytes are
+    // the zero-extended template row shifted by n bytes (chunk 0) or its overflow (chunk 1)
+    if (P <= MS_PMAX && !p.dot4 && !p.generic) {
+        const int NS = (P + 1) / 2;
+        const int chm = s_chmask | 8;
+        const int total = 4 * NS * 64;
+        for (int e = tid; e < total; e += 256) {
+            const int lane = e & 63;
+            const int sp = e >> 6;
+            const int step = sp % NS, type = sp / NS;
+            if (!((chm >> type) & 1)) continue;
+            const int n = lane & 15, g = lane >> 4;
+            const int row = 2 * step + (g >> 1);
+            unsigned long long lo = 0, hi = 0;
+            if (row < P) {
+                const uint8_t* src = type < 3 ? (const uint8_t*)&s_t[type][row * P] : &s_k[row * P];
+                for (int c = 0; c < P; ++c) {
+                    const unsigned long long byte = src[c];
+                    if (c < 8) lo |= byte << (8 * c);
+                    else hi |= byte << (8 * (c - 8));
+                }
+            }
+            unsigned long long olo, ohi;
+            if (!(g & 1)) {               // bytes j = 0..15 hold columns j - n: shift left by n bytes
+                const int sh = 8 * n;
+                if (sh == 0) { olo = lo; ohi = hi; }
+                else if (sh < 64) { olo = lo << sh; ohi = (hi << sh) | (lo >> (64 - sh)); }
+                else if (sh == 64) { olo = 0; ohi = lo; }
+                else { olo = 0; ohi = lo << (sh - 64); }
+            } else {                      // columns 16 + j - n: shift right by 16 - n bytes
+                const int sh = 8 * (16 - n);
+                if (sh >= 128) { olo = 0; ohi = 0; }
+                else if (sh > 64) { olo = hi >> (sh - 64); ohi = 0; }
+                else if (sh == 64) { olo = hi; ohi = 0; }
+                else { olo = (lo >> sh) | (hi << (64 - sh)); ohi = hi >> sh; }
+            }
+            uint4 o;
+            o.x = (uint32_t)olo; o.y = (uint32_t)(olo >> 32); o.z = (uint32_t)ohi; o.w = (uint32_t)(ohi >> 32);
+            ((uint4*)d->tmplB)[e] = o;
+        }
+    }
     if (tid == 0) {
         const int rowmask = s_rowmask;
         d->live = 1;
@@ -678,6 +730,7 @@ __global__ __launch_bounds__(256) void k_select(Params p) {
         d->clipped = (ph != P || pw != P) ? 1 : 0;
         d->ncy = H - ph + 1; d->ncx = W - pw + 1;
         d->soff = s_soff;
+        d->soff2 = s_soff + 24576 * s_nk;
         d->rowmask = rowmask;
         d->chmask = s_chmask;
         d->cnew = cnew_t;
@@ -801,7 +854,7 @@ __global__ __launch_bounds__(256) void k_search(Params p) {
     const int chmask = d->chmask | 0x18;
     // stage the byte planes of this tile (zero beyond the image): 16-byte chunks, all of a
     // thread's loads issued before the first LDS store
-    const uint8_t* pl = p.planes + (size_t)b * 5 * H * p.Wp;
+    const uint8_t* pl = p.planes + (size_t)b * CRIM_NPL * H * p.Wp;
     {
         constexpr int NIT = (NCHUNK + 255) / 256;
         uint4 v[NIT];
@@ -930,6 +983,230 @@ __global__ __launch_bounds__(256) void k_search(Params p) {
     block_min_emit(p, b, bc, bi, s_c, s_i);
 }
 
+// Matrix-core search.  For one template row t[0..P) and 16 x shifts n, the 32 x 16 matrix
+// B[k][n] = t[k - n] turns the correlation of a 32-byte image segment into a matrix product:
+// (A * B)[m][n] = sum_k img[16m + k] * t[k - n] is the row correlation at x origin 16m + n when
+// row m of A is the 32 bytes starting at byte 16m.  One v_mfma_i32_16x16x64_i8 handles two
+// template rows (K = 2 x 32) for 16 chunks x 16 shifts = 256 consecutive x origins of one origin
+// row; the image fragment of rows (r, r+1) serves every (origin row y, step s) with y + 2s = r,
+// so each fragment is read from LDS once and used up to (P+1)/2 times.
+// Exact integer arithmetic: signed bytes, int32 accumulators.
+//   S_reference = 256 * sum k*h + sum k*l - 2 * sum_ch sum (Lab_ch-128) * k*(T_ch-128) + soff2
+// is built in ONE accumulator: the h-digit plane first, times -128, plus the cross terms, times -2,
+// plus the l-digit plane.  Inadmissible windows start from 2^20, i.e. end 2^28 too high.
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+// CHROMA = false serves engines whose images are all grey: only the L channel and the two Q
+// digit planes are staged (3 LDS slots instead of 5, twice the blocks per CU).
+template <int P, bool CHROMA>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CHROMA || P > 11) ? 1 : 3, (CHROMA || P > 11) ? 2 : 3)))
+void k_search_mfma(Params p) {
+    constexpr int NS = (P + 1) / 2;
+    constexpr int R = MS_R;
+    constexpr int NF = R + 2 * NS - 2;          // image fragments per wave and plane
+    constexpr int LROWS = MS_ROWS + 2 * NS - 1; // staged rows per plane
+    constexpr int C16 = MS_PITCH / 16;          // 16-byte chunks per staged row
+    constexpr int NCH = LROWS * C16;
+    constexpr int NIT = (NCH + 255) / 256;
+    constexpr int POISON = 1 << 20;
+    constexpr int NSLOT = CHROMA ? 5 : 3;       // LDS slots: Lab channel(s), l digit, h digit
+    constexpr int NCC = CHROMA ? 3 : 1;         // cross-term channels
+    constexpr int SLOT_L = NSLOT - 2, SLOT_H = NSLOT - 1;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[NSLOT][LROWS][MS_PITCH];
+    __shared__ double s_c[4];
+    __shared__ unsigned s_i[4];
+    __shared__ int s_bound;
+
+    const int b = p.b0 + blockIdx.z;
+    const Desc* __restrict__ d = p.desc + b;
+    if (!d->live) return;
+    const int ncy = d->ncy, ncx = d->ncx;
+    const int y0 = (p.sy0 + blockIdx.y) * MS_ROWS, x0 = blockIdx.x * MS_W;
+    if (y0 >= ncy || x0 >= ncx) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    STAMP(32);
+    if (tid == 0) s_bound = __hip_atomic_load(&p.st[b].bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int H = p.H, W = p.W;
+    const size_t HW = (size_t)H * W;
+    const uint8_t* inv = p.invalid + (size_t)b * H * p.Wi;
+    const uint8_t* mask = p.mask + b * HW;
+    const int clipped = d->clipped;
+    // A channel whose template k*(T-128) is zero everywhere adds nothing to the cross term.
+    const int chmask = d->chmask & (CHROMA ? 7 : 1);
+
+    // Accumulator element j of origin row yy in this lane is the window at
+    // (y0 + wv*R + yy, x0 + 16*(4*(lane>>4) + j) + (lane&15)).
+    const int wx = x0 + 64 * (lane >> 4) + (lane & 15);
+    const int wy = y0 + wv * R;
+
+    // ---- every global load of the prologue is issued before the first is used: window validity
+    // bytes (addresses clamped into the map, range test applied afterwards), template fragments
+    // (layout: Desc::tmplB), plane chunks.
+    uint8_t iv[R][4];
+    if (!clipped) {
+#pragma unroll
+        for (int yy = 0; yy < R; ++yy)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int y = imin(wy + yy, ncy - 1), x = imin(wx + 16 * j, ncx - 1);
+                iv[yy][j] = inv[(size_t)y * p.Wi + x];
+            }
+    }
+    v4i Bk[NS], Bc[NCC][NS];
+    {
+        const v4i* tb = (const v4i*)d->tmplB + lane;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) Bk[s] = tb[(3 * NS + s) * 64];
+#pragma unroll
+        for (int t = 0; t < NCC; ++t) {
+            if (!((chmask >> t) & 1)) continue;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) Bc[t][s] = tb[(t * NS + s) * 64];
+        }
+    }
+    const uint8_t* pl = p.planes + (size_t)b * CRIM_NPL * H * p.Wp;
+    int loff[NIT];
+    uint4 v[NSLOT][NIT];
+    {
+        int goff[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int c = tid + k * 256;
+            const int row = c / C16, c16 = c - row * C16;
+            const int gy = y0 + row, gx = x0 + 16 * c16;
+            loff[k] = c < NCH ? row * MS_PITCH + 16 * c16 : -1;
+            goff[k] = (c < NCH && gy < H && gx + 16 <= p.Wp) ? gy * p.Wp + gx : -1;
+        }
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            if (s < NCC && !((chmask >> s) & 1)) continue;
+            const int plane = s < NCC ? s : (s - NCC + 5);
+            const uint8_t* src = pl + (size_t)plane * H * p.Wp;
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) {
+                v[s][k] = make_uint4(0, 0, 0, 0);
+                if (goff[k] >= 0) v[s][k] = *(const uint4*)(src + goff[k]);
+            }
+        }
+    }
+
+    v4i acc[R];
+    int anyvalid = 0;
+    if (!clipped) {
+#pragma unroll
+        for (int yy = 0; yy < R; ++yy)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int bad = (wy + yy >= ncy || wx + 16 * j >= ncx) ? 1 : (int)iv[yy][j];
+                acc[yy][j] = bad ? POISON : 0;
+                anyvalid |= !bad;
+            }
+    } else {
+        for (int yy = 0; yy < R; ++yy)
+            for (int j = 0; j < 4; ++j) {
+                const int y = wy + yy, x = wx + 16 * j;
+                const int ok = (y < ncy && x < ncx && window_valid(p, d, inv, mask, y, x)) ? 1 : 0;
+                acc[yy][j] = ok ? 0 : POISON;
+                anyvalid |= ok;
+            }
+    }
+    if (!__syncthreads_or(anyvalid)) return;
+    STAMP(33);
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+        if (s < NCC && !((chmask >> s) & 1)) continue;
+#pragma unroll
+        for (int k = 0; k < NIT; ++k)
+            if (loff[k] >= 0) *(uint4*)(&lds[s][0][0] + loff[k]) = v[s][k];
+    }
+    STAMP(34);
+    __syncthreads();
+    STAMP(35);
+
+    if (__any(anyvalid)) {
+        const int g = lane >> 4;
+        const int aoff = (wv * R + (g >> 1)) * MS_PITCH + 16 * ((lane & 15) + (g & 1));
+        auto plane_pass = [&](int slot, const v4i* Bf) {
+            const uint8_t* base = &lds[slot][0][0] + aoff;
+#pragma unroll
+            for (int r = 0; r < NF; ++r) {
+                const v4i F = *(const v4i*)(base + r * MS_PITCH);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const int yy = r - 2 * s;
+                    if (yy >= 0 && yy < R)
+                        acc[yy] = __builtin_amdgcn_mfma_i32_16x16x64_i8(F, Bf[s], acc[yy], 0, 0, 0);
+                }
+            }
+        };
+        plane_pass(SLOT_H, Bk);
+#pragma unroll
+        for (int yy = 0; yy < R; ++yy) acc[yy] *= -128;
+#pragma unroll
+        for (int t = 0; t < NCC; ++t)
+            if ((chmask >> t) & 1) plane_pass(t, Bc[t]);
+#pragma unroll
+        for (int yy = 0; yy < R; ++yy) acc[yy] *= -2;
+        plane_pass(SLOT_L, Bk);
+    }
+
+    STAMP(36);
+    // Same two-phase pricing as the vector kernel: a window's cost is at least its integer S.
+    double bc = INFINITY;
+    unsigned bi = 0xffffffffu;
+    const int soff = d->soff2;
+    int smin = 0x7fffffff, kidx = -1;
+    if (anyvalid) {
+#pragma unroll
+        for (int yy = 0; yy < R; ++yy)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (acc[yy][j] < smin) { smin = acc[yy][j]; kidx = yy * 4 + j; }
+        if (smin >= (POISON << 7)) kidx = -1;
+    }
+    const int gbound = s_bound;
+    if (kidx >= 0 && (long long)smin + soff <= (long long)gbound) {
+        const int y = wy + (kidx >> 2), x = wx + 16 * (kidx & 3);
+        bc = cand_cost(d, smin + soff, y, x);
+        bi = (unsigned)y * (unsigned)ncx + (unsigned)x;
+        const double ubd = floor(bc) + 1.0;
+        const int ub = ubd < 2147483647.0 ? (int)ubd : 0x7fffffff;
+        if (ub < gbound) atomicMin(&s_bound, ub);
+    }
+    STAMP(37);
+    __syncthreads();
+    STAMP(38);
+    const int ub = s_bound;
+    if (kidx >= 0) {
+        const long long lim = (long long)ub - soff;
+        const int ublocal = lim > (long long)(POISON << 7) - 1 ? (POISON << 7) - 1 : (int)lim;
+        // which of the other windows can still reach the bound (usually none)
+        unsigned todo = 0;
+#pragma unroll
+        for (int yy = 0; yy < R; ++yy)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (acc[yy][j] <= ublocal) todo |= 1u << (yy * 4 + j);
+        todo &= ~(1u << kidx);
+        if (todo) {
+#pragma unroll
+            for (int yy = 0; yy < R; ++yy)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (todo & (1u << (yy * 4 + j))) {
+                        const int y = wy + yy, x = wx + 16 * j;
+                        const double c = cand_cost(d, acc[yy][j] + soff, y, x);
+                        const unsigned idx = (unsigned)y * (unsigned)ncx + (unsigned)x;
+                        if (better_cost(c, idx, bc, bi)) { bc = c; bi = idx; }
+                    }
+        }
+    }
+    STAMP(39);
+    if (tid == 0 && ub < gbound) atomicMin(&p.st[b].bound, ub);
+    block_min_emit(p, b, bc, bi, s_c, s_i);
+    STAMP(40);
+}
+
 // Unspecialised search for any patch edge: one origin at a time, planes read from global
 // memory, templates from the flat byte arrays.
 __global__ __launch_bounds__(256) void k_search_generic(Params p) {
@@ -946,7 +1223,7 @@ __global__ __launch_bounds__(256) void k_search_generic(Params p) {
     const size_t HW = (size_t)H * W;
     const uint8_t* inv = p.invalid + (size_t)b * H * p.Wi;
     const uint8_t* mask = p.mask + b * HW;
-    const uint8_t* pl = p.planes + (size_t)b * 5 * H * p.Wp;
+    const uint8_t* pl = p.planes + (size_t)b * CRIM_NPL * H * p.Wp;
     const size_t PS = (size_t)H * p.Wp;
     const int ph = d->ph, pw = d->pw, soff = d->soff;
     double bc = INFINITY;
@@ -1031,7 +1308,7 @@ __global__ __launch_bounds__(256) void k_update(Params p) {
     __shared__ unsigned s_src;
     __shared__ double s_cost;
     __shared__ int s_filled;
-    __shared__ uint8_t s_px[PM * PM][9];   // source pixel: B,G,R, 5 planes, grey
+    __shared__ uint8_t s_px[PM * PM][4 + CRIM_NPL];   // source pixel: B,G,R, the planes, grey
     __shared__ uint8_t s_m[MR * MR];    // mask around the patch, updated as pixels are filled
     __shared__ uint8_t s_m0[MR * MR];   // the same before this iteration's fill
     __shared__ uint8_t s_g[GR * GR];
@@ -1064,7 +1341,7 @@ __global__ __launch_bounds__(256) void k_update(Params p) {
     uint8_t* mask = p.mask + b * HW;
     uint8_t* bgr = p.bgr + b * HW * 3;
     uint8_t* grey = p.grey + b * HW;
-    uint8_t* planes = p.planes + (size_t)b * 5 * H * p.Wp;
+    uint8_t* planes = p.planes + (size_t)b * CRIM_NPL * H * p.Wp;
     const size_t PS = (size_t)H * p.Wp;
     double* cnxt = p.conf + ((size_t)b * 2 + (cur ^ 1)) * HW;
 
@@ -1143,13 +1420,13 @@ __global__ __launch_bounds__(256) void k_update(Params p) {
         const int i = e / pw, j = e - i * pw;
         const size_t s = (size_t)(sy + i) * W + sx + j;
         const size_t so = (size_t)(sy + i) * p.Wp + sx + j;
-        uint8_t v[9];
+        uint8_t v[4 + CRIM_NPL];
         v[0] = bgr[3 * s]; v[1] = bgr[3 * s + 1]; v[2] = bgr[3 * s + 2];
 #pragma unroll
-        for (int k = 0; k < 5; ++k) v[3 + k] = planes[k * PS + so];
-        v[8] = grey[s];
+        for (int k = 0; k < CRIM_NPL; ++k) v[3 + k] = planes[k * PS + so];
+        v[3 + CRIM_NPL] = grey[s];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) s_px[e][k] = v[k];
+        for (int k = 0; k < 4 + CRIM_NPL; ++k) s_px[e][k] = v[k];
     }
     __syncthreads();
     STAMP(18);
@@ -1163,12 +1440,12 @@ __global__ __launch_bounds__(256) void k_update(Params p) {
         if (s_m0[(i + mg) * MR + (j + mg)]) {
             bgr[3 * q] = s_px[e][0]; bgr[3 * q + 1] = s_px[e][1]; bgr[3 * q + 2] = s_px[e][2];
             const size_t qo = (size_t)yy * p.Wp + xx;
-            for (int k = 0; k < 5; ++k) planes[k * PS + qo] = s_px[e][3 + k];
-            grey[q] = s_px[e][8];
+            for (int k = 0; k < CRIM_NPL; ++k) planes[k * PS + qo] = s_px[e][3 + k];
+            grey[q] = s_px[e][3 + CRIM_NPL];
             cnxt[q] = cnew;
             mask[q] = 0;
             s_m[(i + mg) * MR + (j + mg)] = 0;
-            s_g[(i + 2) * GR + (j + 2)] = s_px[e][8];
+            s_g[(i + 2) * GR + (j + 2)] = s_px[e][3 + CRIM_NPL];
             atomicOr(&s_fill[e >> 5], 1u << (e & 31));
             ++filled;
         }

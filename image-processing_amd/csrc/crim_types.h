@@ -7,6 +7,16 @@
 #define CRIM_TILE 16          // edge of a priority-scan tile (pixels)
 #define CRIM_PMAX CRIM_MAX_PATCH
 #define CRIM_NDMAX ((CRIM_PMAX + 6) / 4)
+#define CRIM_NPL 7            // search byte planes per image
+
+// Matrix-core search tiling: a 256-thread block scores MS_W x MS_ROWS window origins; each of its
+// 4 waves owns MS_R consecutive origin rows.  Patch edges up to MS_PMAX.
+#define MS_W 256
+#define MS_R 8
+#define MS_ROWS (4 * MS_R)
+#define MS_PITCH (MS_W + 16)
+#define MS_PMAX 15
+#define MS_NSMAX ((MS_PMAX + 1) / 2)
 
 // Search-kernel tiling: a 256-thread block scores SB_TXG*4 x SB_TYT*SB_R candidate origins.
 #define SB_TXG 32   // groups of 4 consecutive x origins per block row
@@ -22,7 +32,7 @@ struct ImgState {
     int cur;         // which of the two confidence buffers is current
     int remaining;   // masked pixels left
     unsigned tcount; // entries in the priority-stage tile list
-    int pad0;
+    int chroma;      // some pixel of the image has Lab a or b different from 128
     unsigned pcount; // entries in this image's priority partial list
     unsigned scount; // entries in this image's search partial list
     int stalled;     // an iteration filled nothing while pixels remained
@@ -52,6 +62,8 @@ struct Desc {
     int clipped;         // ph or pw smaller than the full patch edge
     int ncy, ncx;        // candidate grid: H-ph+1, W-pw+1
     int soff;            // S_reference = S_centred + soff
+    int soff2;           // S_reference = 256*sum k*h + sum k*l - 2*cross + soff2 (balanced Q digits)
+    int pad2;
     int rowmask;         // bit i set: template row i has at least one known pixel
     int chmask;          // bit c set: k * (Lab_c - 128) is nonzero somewhere in the template
     int pad1;
@@ -64,6 +76,12 @@ struct Desc {
     // k*T per Lab channel (signed), 3 = k, 4 = 255*k (unsigned).  Dimensions are the
     // engine's P and ND (compact, not CRIM_PMAX).
     uint32_t tmpl[5 * CRIM_PMAX * 4 * CRIM_NDMAX];
+    // Operand fragments of the matrix-core search: [type][step][lane][4 dwords], type 0..2 =
+    // k*T per Lab channel, 3 = k.  Step s holds template rows 2s and 2s+1; lane (n = lane & 15,
+    // g = lane >> 4) holds, for byte j = 0..15, template row 2s + (g >> 1), column
+    // 16 * (g & 1) + j - n (zero outside the patch): column n of a Toeplitz matrix, so that one
+    // MFMA correlates 16 image chunks with 16 x shifts.  Only written for patch edges <= MS_PMAX.
+    uint32_t tmplB[4 * MS_NSMAX * 64 * 4];
 };
 
 struct Params {
@@ -81,9 +99,12 @@ struct Params {
     int nparts;   // > 0: split search, k_update reduces xchg[0..nparts) instead of the partial list
     int pgrid;    // priority-scan blocks per image
     int generic;  // use the unspecialised search kernel
+    int dot4;     // use the vector dot-product search kernel instead of the matrix-core one
+    int chroma;   // some uploaded image is not grey: the matrix-core search stages all five planes
     long trace_cap;
     uint8_t* bgr;      // [B][H][W][3]
-    uint8_t* planes;   // [B][5][H][Wp]  L-128, a-128, b-128 (int8), Q%255, Q/255 (uint8)
+    uint8_t* planes;   // [B][CRIM_NPL][H][Wp]  L-128, a-128, b-128 (int8), Q%255, Q/255 (uint8),
+                       // and the balanced digits l, h (int8) of Q - 24576 = 256*h + l
     uint8_t* mask;     // [B][H][W]
     uint8_t* grey;     // [B][H][W]
     int* grad;         // [B][H][W] packed (int16 2*gy, int16 2*gx)
