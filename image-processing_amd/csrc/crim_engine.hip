@@ -255,7 +255,20 @@ static void launch_compact(const Params& p, hipStream_t s) {
 
 static size_t priority_lds_bytes(const Params& p) {
     const size_t rs = CRIM_TILE + 2 * p.half;
-    return rs * rs * 12 + CRIM_TILE * CRIM_TILE * 4 + (CRIM_TILE + 2) * (CRIM_TILE + 2) + 16;
+    return rs * rs * 16 + CRIM_TILE * CRIM_TILE * 4 + (CRIM_TILE + 2) * (CRIM_TILE + 2) + 16;
+}
+
+static void launch_priority(const Params& p, hipStream_t s) {
+    const dim3 grid(p.pgrid, p.B), block(64);
+    const size_t lds = priority_lds_bytes(p);
+    switch (p.P) {
+        case 3: hipLaunchKernelGGL(k_priority<3>, grid, block, lds, s, p); break;
+        case 5: hipLaunchKernelGGL(k_priority<5>, grid, block, lds, s, p); break;
+        case 7: hipLaunchKernelGGL(k_priority<7>, grid, block, lds, s, p); break;
+        case 9: hipLaunchKernelGGL(k_priority<9>, grid, block, lds, s, p); break;
+        case 11: hipLaunchKernelGGL(k_priority<11>, grid, block, lds, s, p); break;
+        default: hipLaunchKernelGGL(k_priority<0>, grid, block, lds, s, p); break;
+    }
 }
 
 #define COMPACT_PERIOD 16
@@ -264,7 +277,7 @@ static size_t priority_lds_bytes(const Params& p) {
 // given, bracket the search launch.
 static void launch_iteration(const Params& p, hipStream_t s, hipEvent_t ev0 = nullptr,
                              hipEvent_t ev1 = nullptr) {
-    hipLaunchKernelGGL(k_priority, dim3(p.pgrid, p.B), dim3(64), priority_lds_bytes(p), s, p);
+    launch_priority(p, s);
     hipLaunchKernelGGL(k_select, dim3(p.B), dim3(256), 0, s, p);
     if (ev0) (void)hipEventRecord(ev0, s);
     launch_search(p, s);
@@ -596,7 +609,7 @@ static int run_split(crim_engine* h, long max_iters) {
         if (need <= 0) break;
         for (long it = 0; it < need; ++it) {
             if ((done + it) > 0 && (done + it) % COMPACT_PERIOD == 0) launch_compact(p, ln.stream);
-            hipLaunchKernelGGL(k_priority, dim3(p.pgrid, p.B), dim3(64), priority_lds_bytes(p), ln.stream, p);
+            launch_priority(p, ln.stream);
             hipLaunchKernelGGL(k_select, dim3(p.B), dim3(256), 0, ln.stream, p);
             for (int part = 0; part < parts; ++part) {
                 if (h->split_rank >= 0 && part != h->split_rank) continue;

@@ -45,14 +45,17 @@ __device__ __forceinline__ const_u32_ptr as_const_u32(const void* p) {
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 
-// A rectangular window of a 2-D field: element (y, x) in image coordinates lives at
-// base[(y - oy) * pitch + (x - ox)].  The same code reads whole frames in global memory
-// (oy = ox = 0, pitch = W) and tiles staged in LDS.
+// A rectangular window of a 2-D field: element (y, x) in image coordinates lives `stride` bytes
+// apart at base + ((y - oy) * pitch + (x - ox)) * stride.  The same code reads whole frames in
+// global memory (oy = ox = 0, pitch = W, stride = sizeof(T)) and the interleaved records of a tile
+// staged in LDS.
 template <typename T>
 struct View {
-    const T* base;
-    int pitch, oy, ox;
-    __device__ __forceinline__ T at(int y, int x) const { return base[(y - oy) * pitch + (x - ox)]; }
+    const unsigned char* base;
+    int pitch, oy, ox, stride;
+    __device__ __forceinline__ T at(int y, int x) const {
+        return *(const T*)(base + (size_t)((y - oy) * pitch + (x - ox)) * stride);
+    }
 };
 
 // Reads element e of a row-major ph x pw window of the confidence map (flattened order).
@@ -389,12 +392,42 @@ __global__ __launch_bounds__(256) void k_tiles(Params p) {
     if (threadIdx.x == 0) st->tcount = s_n;
 }
 
+// Data term (criminisi_inpainter.py:129-214) and priority (:112) of a front pixel from its new
+// confidence, its 3x3 mask neighbourhood and the packed gradient at the patch's first gradient
+// maximum.
+__device__ __forceinline__ FrontEval finish_front_pixel(double cnew, const int nb[9], int F, int bpk) {
+    FrontEval out;
+    out.cnew = cnew;
+    const double a = nb[0], b = nb[1], c = nb[2], d = nb[3], f = nb[5], g = nb[6], h = nb[7],
+                 k = nb[8];
+    const double nx = .25 * a - .25 * c + .5 * d - .5 * f + .25 * g - .25 * k;
+    const double ny = -.25 * a - .5 * b - .25 * c + .25 * g + .5 * h + .25 * k;
+    double nrm = sqrt(ny * ny + nx * nx);
+    if (nrm == 0) nrm = 1;
+    const double ux = nx / nrm, uy = ny / nrm;
+    const int by = (int)(short)(bpk & 0xffff), bx = bpk >> 16;
+    const double Gy = (double)by * 0.5, Gx = (double)bx * 0.5;
+    const double t0 = ux * Gy, t1 = uy * Gx;
+    out.data = sqrt(t0 * t0 + t1 * t1) + 0.001;
+    out.prio = out.cnew * out.data * (double)F;
+    return out;
+}
+
 // grid (pgrid, B), one wave per block; block g of image b walks entries g, g + pgrid, ... of
 // that image's tile list.  Per tile: the confidence and gradient fields of the tile grown by
-// the patch half-width and the mask grown by one pixel are staged in LDS; front pixels are
-// compacted; groups of PG lanes evaluate one front pixel each from LDS.  Every front pixel gets
-// its new confidence (written to the other confidence buffer: the update is Jacobi-style,
-// :115-127) and its priority; the block emits its best (priority, position).
+// the patch half-width (one 16-byte record per pixel: confidence, 4*|gradient|^2 << 10, packed
+// gradient) and the mask grown by one pixel are staged in LDS; front pixels are compacted;
+// groups of PG lanes evaluate one front pixel each from LDS.  Every front pixel gets its new
+// confidence (written to the other confidence buffer: the update is Jacobi-style, :115-127) and
+// its priority; the block emits its best (priority, position).
+//
+// PT > 0 is the compile-time patch edge of the fast path for pixels whose patch lies inside the
+// image (PT*PT <= 128, so NumPy's pairwise sum is a single 8-accumulator leaf): lane l of a group
+// owns accumulators 2l and 2l+1, i.e. flattened elements 8i + 2l + k, whose LDS offsets relative to
+// the patch corner are the same for every pixel and are computed once per kernel.  The same
+// elements feed the gradient scan: the largest key (4*|g|^2 << 10) | (1023 - e) is the first
+// maximum in flattened order.  Other pixels (clipped patches, larger PT) take the general path.
+template <int PT>
 __global__ __launch_bounds__(64) void k_priority(Params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = p.b0 + blockIdx.y;
@@ -406,11 +439,10 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
     const int nt = (int)st->tcount;
     STAMP(1);
     if ((int)blockIdx.x >= nt) return;
-    const int RS = CRIM_TILE + 2 * half;          // edge of the staged region
-    const int MS = CRIM_TILE + 2;                 // edge of the staged mask
-    double* s_conf = (double*)smem;
-    int* s_grad = (int*)(s_conf + RS * RS);
-    int* s_list = s_grad + RS * RS;
+    const int RS = PT > 0 ? CRIM_TILE + PT - 1 : CRIM_TILE + 2 * half;   // edge of the staged region
+    constexpr int MS = CRIM_TILE + 2;                                    // edge of the staged mask
+    uint4* s_el = (uint4*)smem;
+    int* s_list = (int*)(s_el + RS * RS);
     uint8_t* s_mask = (uint8_t*)(s_list + CRIM_TILE * CRIM_TILE);
     const int* tl = p.tlist + (size_t)b * p.tcap;
     const int* tf = p.tfront + (size_t)b * p.tnx * p.tny;
@@ -424,31 +456,59 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
     double bestP = -1.0;
     int bestI = 0x7fffffff;
 
+    constexpr int NE = PT > 0 ? (PT * PT) / 8 : 1;
+    int off[2 * NE];
+    if (PT > 0) {
+#pragma unroll
+        for (int i = 0; i < NE; ++i)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int e = 8 * i + 2 * l + k;
+                const int row = e / (PT > 0 ? PT : 1), col = e - row * PT;
+                off[2 * i + k] = (row * RS + col) * 16;
+            }
+    }
+    // staging geometry: lanes cover one (RS <= 32) or half a (RS <= 64) staged row per pass
+    const int sh = RS <= 32 ? 5 : 6;
+    const int rpp = 64 >> sh;
+    const int scol = lane & ((1 << sh) - 1), srow = lane >> sh;
+
     for (int ti = blockIdx.x; ti < nt; ti += gridDim.x) {
         const int tile = tl[ti];
         if (tf[tile] <= 0) continue;              // block-uniform
         const int tY = tile / p.tnx, tX = tile - tY * p.tnx;
         const int ty0 = tY * CRIM_TILE, tx0 = tX * CRIM_TILE;
         const int ry0 = ty0 - half, rx0 = tx0 - half;
-        // batches of 8 elements per lane so that 16 loads are in flight before the first store
-        for (int i0 = lane; i0 < RS * RS; i0 += 64 * 8) {
-            double cv[8];
-            int gv[8];
+        // Pixels beyond the image are never read (patches are clipped to it): their records are
+        // filled from the clamped position.  Eight rows of loads are in flight per batch.
+        {
+            const int xx = imin(imax(rx0 + scol, 0), W - 1);
+            for (int rb = srow; rb < RS; rb += 8 * rpp) {
+                double cv[8];
+                int gv[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int i = i0 + 64 * k;
-                const int yy = ry0 + i / RS, xx = rx0 + i % RS;
-                cv[k] = 0.0;
-                gv[k] = 0;
-                if (i < RS * RS && yy >= 0 && yy < H && xx >= 0 && xx < W) {
-                    cv[k] = ccur[(size_t)yy * W + xx];
-                    gv[k] = grad[(size_t)yy * W + xx];
+                for (int k = 0; k < 8; ++k) {
+                    const int row = rb + k * rpp;
+                    cv[k] = 0.0; gv[k] = 0;
+                    if (row < RS && scol < RS) {
+                        const int yy = imin(imax(ry0 + row, 0), H - 1);
+                        const int idx = yy * W + xx;
+                        cv[k] = ccur[idx];
+                        gv[k] = grad[idx];
+                    }
                 }
-            }
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int i = i0 + 64 * k;
-                if (i < RS * RS) { s_conf[i] = cv[k]; s_grad[i] = gv[k]; }
+                for (int k = 0; k < 8; ++k) {
+                    const int row = rb + k * rpp;
+                    if (row < RS && scol < RS) {
+                        const int gy2 = (int)(short)(gv[k] & 0xffff), gx2 = gv[k] >> 16;
+                        uint4 el;
+                        el.x = (uint32_t)__double2loint(cv[k]); el.y = (uint32_t)__double2hiint(cv[k]);
+                        el.z = (uint32_t)(gy2 * gy2 + gx2 * gx2) << 10;
+                        el.w = (uint32_t)gv[k];
+                        s_el[row * RS + scol] = el;
+                    }
+                }
             }
         }
         {
@@ -482,8 +542,8 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
             n += __popcll(bal);
         }
         __syncthreads();
-        View<double> vconf; vconf.base = s_conf; vconf.pitch = RS; vconf.oy = ry0; vconf.ox = rx0;
-        View<int> vgrad; vgrad.base = s_grad; vgrad.pitch = RS; vgrad.oy = ry0; vgrad.ox = rx0;
+        View<double> vconf; vconf.base = (const unsigned char*)s_el; vconf.pitch = RS; vconf.oy = ry0; vconf.ox = rx0; vconf.stride = 16;
+        View<int> vgrad; vgrad.base = (const unsigned char*)s_el + 12; vgrad.pitch = RS; vgrad.oy = ry0; vgrad.ox = rx0; vgrad.stride = 16;
         for (int e = grp; e < n; e += 64 / PG) {
             const int pi = s_list[e];
             const int py = pi >> 4, px = pi & 15;
@@ -495,7 +555,42 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) nb[a * 3 + c] = m0[a * MS + c];
             const int F = front_from_nb(nb);
-            const FrontEval ev = eval_front_pixel(p, vgrad, vconf, fy, fx, F, nb, l);
+            FrontEval ev;
+            if (PT > 0 && PG == 4 && fy >= half && fy + half < H && fx >= half && fx + half < W) {
+                const unsigned char* eb = (const unsigned char*)s_el + (py * RS + px) * 16;
+                double r0 = 0.0, r1 = 0.0;
+                unsigned best = 0;
+                const unsigned kb = 1023u - 2u * (unsigned)l;
+#pragma unroll
+                for (int i = 0; i < NE; ++i) {
+                    const uint4 a = *(const uint4*)(eb + off[2 * i]);
+                    const uint4 c = *(const uint4*)(eb + off[2 * i + 1]);
+                    const double ca = __hiloint2double((int)a.y, (int)a.x);
+                    const double cc = __hiloint2double((int)c.y, (int)c.x);
+                    if (i == 0) { r0 = ca; r1 = cc; } else { r0 += ca; r1 += cc; }
+                    const unsigned ka = a.z + (kb - 8u * i), kc = c.z + (kb - 8u * i - 1u);
+                    best = ka > best ? ka : best;
+                    best = kc > best ? kc : best;
+                }
+                constexpr int EL = PT * PT - 1;   // the one tail element: PT*PT = 1 (mod 8)
+                const uint4 tl_ = *(const uint4*)(eb + ((PT - 1) * RS + (PT - 1)) * 16);
+                double t = r0 + r1;
+                t = t + __shfl_xor(t, 1, PG);
+                t = t + __shfl_xor(t, 2, PG);
+                t += __hiloint2double((int)tl_.y, (int)tl_.x);
+                unsigned ob = (unsigned)__shfl_xor((int)best, 1, PG);
+                best = ob > best ? ob : best;
+                ob = (unsigned)__shfl_xor((int)best, 2, PG);
+                best = ob > best ? ob : best;
+                const unsigned kt = tl_.z + (1023u - (unsigned)EL);
+                best = kt > best ? kt : best;
+                const int be = 1023 - (int)(best & 1023u);
+                const int brow = be / (PT > 0 ? PT : 1), bcol = be - brow * PT;
+                const int bpk = (int)((const uint4*)eb)[brow * RS + bcol].w;
+                ev = finish_front_pixel(t / (double)p.psq, nb, F, bpk);
+            } else {
+                ev = eval_front_pixel(p, vgrad, vconf, fy, fx, F, nb, l);
+            }
             if (l == 0) {
                 const int pos = fy * W + fx;
                 cnxt[pos] = ev.cnew;
@@ -506,9 +601,9 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
     }
     STAMP(2);
     // wave arg-max: highest priority, lowest row-major index on ties (np.argmax, :217)
-    for (int off = 32; off > 0; off >>= 1) {
-        const double op = __shfl_down(bestP, off);
-        const int oi = __shfl_down(bestI, off);
+    for (int off_ = 32; off_ > 0; off_ >>= 1) {
+        const double op = __shfl_down(bestP, off_);
+        const int oi = __shfl_down(bestI, off_);
         if (better_prio(op, oi, bestP, bestI)) { bestP = op; bestI = oi; }
     }
     if (lane == 0 && bestP >= 0.0) {
@@ -537,8 +632,8 @@ __global__ __launch_bounds__(256) void k_fields(Params p, int b, uint8_t* front,
     const size_t i = (size_t)y * p.W + x;
     double dv = 0.001, pv = 0.0;   // off the front the gradient is zero: sqrt(0) + 0.001
     if (F > 0) {
-        View<double> vconf; vconf.base = ccur; vconf.pitch = p.W; vconf.oy = 0; vconf.ox = 0;
-        View<int> vgrad; vgrad.base = p.grad + b * HW; vgrad.pitch = p.W; vgrad.oy = 0; vgrad.ox = 0;
+        View<double> vconf; vconf.base = (const unsigned char*)ccur; vconf.pitch = p.W; vconf.oy = 0; vconf.ox = 0; vconf.stride = 8;
+        View<int> vgrad; vgrad.base = (const unsigned char*)(p.grad + b * HW); vgrad.pitch = p.W; vgrad.oy = 0; vgrad.ox = 0; vgrad.stride = 4;
         const FrontEval ev = eval_front_pixel(p, vgrad, vconf, y, x, F, nb, l);
         dv = ev.data;
         pv = ev.prio;
@@ -995,11 +1090,14 @@ __global__ __launch_bounds__(256) void k_search(Params p) {
 // is built in ONE accumulator: the h-digit plane first, times -128, plus the cross terms, times -2,
 // plus the l-digit plane.  Inadmissible windows start from 2^20, i.e. end 2^28 too high.
 typedef int v4i __attribute__((ext_vector_type(4)));
+#ifndef MS_WPE
+#define MS_WPE(P, CHROMA) (((CHROMA) || (P) > 11) ? 2 : ((P) > 9 ? 3 : 4))
+#endif
 
 // CHROMA = false serves engines whose images are all grey: only the L channel and the two Q
 // digit planes are staged (3 LDS slots instead of 5, twice the blocks per CU).
 template <int P, bool CHROMA>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CHROMA || P > 11) ? 1 : 3, (CHROMA || P > 11) ? 2 : 3)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MS_WPE(P, CHROMA), MS_WPE(P, CHROMA))))
 void k_search_mfma(Params p) {
     constexpr int NS = (P + 1) / 2;
     constexpr int R = MS_R;
@@ -1053,17 +1151,9 @@ void k_search_mfma(Params p) {
             }
     }
     v4i Bk[NS], Bc[NCC][NS];
-    {
-        const v4i* tb = (const v4i*)d->tmplB + lane;
+    const v4i* tb = (const v4i*)d->tmplB + lane;
 #pragma unroll
-        for (int s = 0; s < NS; ++s) Bk[s] = tb[(3 * NS + s) * 64];
-#pragma unroll
-        for (int t = 0; t < NCC; ++t) {
-            if (!((chmask >> t) & 1)) continue;
-#pragma unroll
-            for (int s = 0; s < NS; ++s) Bc[t][s] = tb[(t * NS + s) * 64];
-        }
-    }
+    for (int s = 0; s < NS; ++s) Bk[s] = tb[(3 * NS + s) * 64];
     const uint8_t* pl = p.planes + (size_t)b * CRIM_NPL * H * p.Wp;
     int loff[NIT];
     uint4 v[NSLOT][NIT];
@@ -1118,6 +1208,14 @@ void k_search_mfma(Params p) {
 #pragma unroll
         for (int k = 0; k < NIT; ++k)
             if (loff[k] >= 0) *(uint4*)(&lds[s][0][0] + loff[k]) = v[s][k];
+    }
+    // the cross-term fragments are requested once the staging registers are free; the barrier and
+    // the first plane pass cover their latency
+#pragma unroll
+    for (int t = 0; t < NCC; ++t) {
+        if (!((chmask >> t) & 1)) continue;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) Bc[t][s] = tb[(t * NS + s) * 64];
     }
     STAMP(34);
     __syncthreads();
