@@ -23,6 +23,7 @@ CRIM_ERR_NOMEM = 5
 FLAG_EAGER = 1
 FLAG_PROFILE = 2
 FLAG_GENERIC_SEARCH = 4
+FLAG_DOT4_SEARCH = 8
 
 MAX_PATCH = 31
 

@@ -72,6 +72,27 @@ def test_border_clipped_patches(p):
     assert_same_as_oracle(img, m, p)
 
 
+@pytest.mark.parametrize("p", [3, 5, 7, 9, 11, 13, 15])
+def test_grey_images_take_the_three_plane_search(p):
+    # a = b = 128 for every grey pixel: the matrix-core search stages 3 planes instead of 5
+    img, m = rand_case(150 + p, 80, 300, noise=False, colour=False)
+    assert_same_as_oracle(img, m, p)
+
+
+@pytest.mark.parametrize("p,colour", [(3, True), (9, True), (9, False), (15, True)])
+def test_vector_dot_product_search_flag(p, colour):
+    img, m = rand_case(170 + p, 72, 140, noise=False, colour=colour, border=(p == 9))
+    assert_same_as_oracle(img, m, p, flags=capi.FLAG_DOT4_SEARCH)
+
+
+def test_wide_image_spans_several_search_tiles():
+    # 600 columns: three 256-origin tiles per row of matrix-core blocks, the last one partial
+    img, m = rand_case(180, 40, 600, noise=True, colour=True)
+    assert_same_as_oracle(img, m, 9)
+    img, m = rand_case(181, 40, 600, noise=False, colour=False, border=True)
+    assert_same_as_oracle(img, m, 7)
+
+
 # patch_size 1 and 2 give a 1x1 patch around a known pixel: the reference never terminates
 @pytest.mark.parametrize("p", [4, 6, 8, 17, 21, 31])
 def test_generic_patch_sizes(p):
