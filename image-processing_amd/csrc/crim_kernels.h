@@ -777,45 +777,14 @@ __global__ __launch_bounds__(256) void k_select(Params p) {
         }
         d->tmpl[e] = v;
     }
-    // operand fragments of the matrix-core search (layout: Desc::tmplB): a lane's 16 bytes are
-    // the zero-extended template row shifted by n bytes (chunk 0) or its overflow (chunk 1)
+    // template rows of the matrix-core search, zero padded to 16 bytes
     if (P <= MS_PMAX && !p.dot4 && !p.generic) {
-        const int NS = (P + 1) / 2;
-        const int chm = s_chmask | 8;
-        const int total = 4 * NS * 64;
-        for (int e = tid; e < total; e += 256) {
-            const int lane = e & 63;
-            const int sp = e >> 6;
-            const int step = sp % NS, type = sp / NS;
-            if (!((chm >> type) & 1)) continue;
-            const int n = lane & 15, g = lane >> 4;
-            const int row = 2 * step + (g >> 1);
-            unsigned long long lo = 0, hi = 0;
-            if (row < P) {
-                const uint8_t* src = type < 3 ? (const uint8_t*)&s_t[type][row * P] : &s_k[row * P];
-                for (int c = 0; c < P; ++c) {
-                    const unsigned long long byte = src[c];
-                    if (c < 8) lo |= byte << (8 * c);
-                    else hi |= byte << (8 * (c - 8));
-                }
-            }
-            unsigned long long olo, ohi;
-            if (!(g & 1)) {               // bytes j = 0..15 hold columns j - n: shift left by n bytes
-                const int sh = 8 * n;
-                if (sh == 0) { olo = lo; ohi = hi; }
-                else if (sh < 64) { olo = lo << sh; ohi = (hi << sh) | (lo >> (64 - sh)); }
-                else if (sh == 64) { olo = 0; ohi = lo; }
-                else { olo = 0; ohi = lo << (sh - 64); }
-            } else {                      // columns 16 + j - n: shift right by 16 - n bytes
-                const int sh = 8 * (16 - n);
-                if (sh >= 128) { olo = 0; ohi = 0; }
-                else if (sh > 64) { olo = hi >> (sh - 64); ohi = 0; }
-                else if (sh == 64) { olo = hi; ohi = 0; }
-                else { olo = (lo >> sh) | (hi << (64 - sh)); ohi = hi >> sh; }
-            }
-            uint4 o;
-            o.x = (uint32_t)olo; o.y = (uint32_t)(olo >> 32); o.z = (uint32_t)ohi; o.w = (uint32_t)(ohi >> 32);
-            ((uint4*)d->tmplB)[e] = o;
+        const int rows = P + 1;
+        for (int e = tid; e < 4 * rows * 16; e += 256) {
+            const int col = e & 15, row = (e >> 4) % rows, type = (e >> 4) / rows;
+            uint8_t v = 0;
+            if (row < P && col < P) v = type < 3 ? (uint8_t)s_t[type][row * P + col] : s_k[row * P + col];
+            d->zrows[type][row][col] = v;
         }
     }
     if (tid == 0) {
@@ -1111,6 +1080,9 @@ void k_search_mfma(Params p) {
     constexpr int NCC = CHROMA ? 3 : 1;         // cross-term channels
     constexpr int SLOT_L = NSLOT - 2, SLOT_H = NSLOT - 1;
     __shared__ __attribute__((aligned(16))) uint8_t lds[NSLOT][LROWS][MS_PITCH];
+    // template rows, [type 0..NCC-1 = k*T per channel, NCC = k][row][48]: 16 zero bytes, the row
+    // padded to 16, 16 zero bytes -- a lane's operand bytes are an unaligned 16-byte window of it
+    __shared__ __attribute__((aligned(16))) uint8_t zl[NCC + 1][2 * NS][48];
     __shared__ double s_c[4];
     __shared__ unsigned s_i[4];
     __shared__ int s_bound;
@@ -1139,7 +1111,7 @@ void k_search_mfma(Params p) {
 
     // ---- every global load of the prologue is issued before the first is used: window validity
     // bytes (addresses clamped into the map, range test applied afterwards), template fragments
-    // (layout: Desc::tmplB), plane chunks.
+    // plane chunks.
     uint8_t iv[R][4];
     if (!clipped) {
 #pragma unroll
@@ -1150,10 +1122,14 @@ void k_search_mfma(Params p) {
                 iv[yy][j] = inv[(size_t)y * p.Wi + x];
             }
     }
-    v4i Bk[NS], Bc[NCC][NS];
-    const v4i* tb = (const v4i*)d->tmplB + lane;
-#pragma unroll
-    for (int s = 0; s < NS; ++s) Bk[s] = tb[(3 * NS + s) * 64];
+    // template rows: one 16-byte chunk per thread, the zero padding by the same threads
+    constexpr int NZ = (NCC + 1) * 2 * NS;
+    uint4 zv = make_uint4(0, 0, 0, 0);
+    if (tid < NZ) {
+        const int row = tid % (2 * NS), type = tid / (2 * NS);
+        if (row < P && (type == NCC || ((chmask >> type) & 1)))
+            zv = *(const uint4*)d->zrows[type == NCC ? 3 : type][row];
+    }
     const uint8_t* pl = p.planes + (size_t)b * CRIM_NPL * H * p.Wp;
     int loff[NIT];
     uint4 v[NSLOT][NIT];
@@ -1209,13 +1185,9 @@ void k_search_mfma(Params p) {
         for (int k = 0; k < NIT; ++k)
             if (loff[k] >= 0) *(uint4*)(&lds[s][0][0] + loff[k]) = v[s][k];
     }
-    // the cross-term fragments are requested once the staging registers are free; the barrier and
-    // the first plane pass cover their latency
-#pragma unroll
-    for (int t = 0; t < NCC; ++t) {
-        if (!((chmask >> t) & 1)) continue;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) Bc[t][s] = tb[(t * NS + s) * 64];
+    if (tid < NZ) {
+        uint4* z = (uint4*)&zl[0][0][0] + 3 * tid;
+        z[0] = make_uint4(0, 0, 0, 0); z[1] = zv; z[2] = make_uint4(0, 0, 0, 0);
     }
     STAMP(34);
     __syncthreads();
@@ -1224,6 +1196,28 @@ void k_search_mfma(Params p) {
     if (__any(anyvalid)) {
         const int g = lane >> 4;
         const int aoff = (wv * R + (g >> 1)) * MS_PITCH + 16 * ((lane & 15) + (g & 1));
+        // Operand fragment of step s: lane (n = lane & 15, g) holds, for byte j = 0..15, template
+        // row 2s + (g >> 1), column 16 * (g & 1) + j - n (zero outside the patch) -- column n of
+        // the Toeplitz matrix -- i.e. the 16 bytes at offset 16 + 16 * (g & 1) - n of the padded row.
+        const int zoff = (g >> 1) * 48 + 16 + 16 * (g & 1) - (lane & 15);
+        auto fragments = [&](int type, v4i* Bf) {
+            const uint8_t* zb = &zl[type][0][0] + (zoff & ~3);
+            const int sh = zoff & 3;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const uint32_t* q = (const uint32_t*)(zb + s * 96);
+                const uint32_t w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3], w4 = q[4];
+                Bf[s][0] = (int)__builtin_amdgcn_alignbyte(w1, w0, sh);
+                Bf[s][1] = (int)__builtin_amdgcn_alignbyte(w2, w1, sh);
+                Bf[s][2] = (int)__builtin_amdgcn_alignbyte(w3, w2, sh);
+                Bf[s][3] = (int)__builtin_amdgcn_alignbyte(w4, w3, sh);
+            }
+        };
+        v4i Bk[NS], Bc[NCC][NS];
+        fragments(NCC, Bk);
+#pragma unroll
+        for (int t = 0; t < NCC; ++t)
+            if ((chmask >> t) & 1) fragments(t, Bc[t]);
         auto plane_pass = [&](int slot, const v4i* Bf) {
             const uint8_t* base = &lds[slot][0][0] + aoff;
 #pragma unroll

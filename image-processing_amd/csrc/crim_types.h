@@ -76,12 +76,9 @@ struct Desc {
     // k*T per Lab channel (signed), 3 = k, 4 = 255*k (unsigned).  Dimensions are the
     // engine's P and ND (compact, not CRIM_PMAX).
     uint32_t tmpl[5 * CRIM_PMAX * 4 * CRIM_NDMAX];
-    // Operand fragments of the matrix-core search: [type][step][lane][4 dwords], type 0..2 =
-    // k*T per Lab channel, 3 = k.  Step s holds template rows 2s and 2s+1; lane (n = lane & 15,
-    // g = lane >> 4) holds, for byte j = 0..15, template row 2s + (g >> 1), column
-    // 16 * (g & 1) + j - n (zero outside the patch): column n of a Toeplitz matrix, so that one
-    // MFMA correlates 16 image chunks with 16 x shifts.  Only written for patch edges <= MS_PMAX.
-    uint32_t tmplB[4 * MS_NSMAX * 64 * 4];
+    // Template rows for the matrix-core search, each zero padded to 16 bytes: [type][row], type
+    // 0..2 = k*T per Lab channel (signed), 3 = k.  Only written for patch edges <= MS_PMAX.
+    uint8_t zrows[4][MS_PMAX + 1][16];
 };
 
 struct Params {

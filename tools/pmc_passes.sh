@@ -24,6 +24,6 @@ for name in ("valu", "lds", "fetch", "write", "grbm"):
         k = r["Kernel_Name"].split("(")[0]
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); 
     for k in agg:
-        if "k_search" in k or k in ("k_priority", "k_update", "k_select"):
+        if "k_search" in k or "k_priority" in k or k in ("k_update", "k_select"):
             print(name, k, {c: round(v, 1) for c, v in agg[k].items()})
 PY
