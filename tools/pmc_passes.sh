@@ -14,16 +14,31 @@ run fetch FETCH_SIZE || exit 1
 run write WRITE_SIZE || exit 1
 run grbm GRBM_GUI_ACTIVE GRBM_COUNT || exit 1
 python3 - <<PY
-import csv, glob, collections
+import csv, glob, collections, json
+summary = {}
 for name in ("valu", "lds", "fetch", "write", "grbm"):
     files = glob.glob("$R/gpurun_out/pmc_%s/*/*counter_collection.csv" % name)
     if not files:
         print(name, "no counter file"); continue
-    agg = collections.defaultdict(lambda: collections.defaultdict(float)); calls = collections.Counter()
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    disp = collections.defaultdict(set)
     for r in csv.DictReader(open(files[0])):
         k = r["Kernel_Name"].split("(")[0]
-        agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); 
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        disp[k].add(r["Dispatch_Id"])
     for k in agg:
         if "k_search" in k or "k_priority" in k or k in ("k_update", "k_select"):
-            print(name, k, {c: round(v, 1) for c, v in agg[k].items()})
+            n = len(disp[k])
+            summary.setdefault(k, {})["launches_" + name] = n
+            for c, v in agg[k].items():
+                summary[k][c + "_per_launch"] = v / n
+            print(name, k, "launches", n, {c: round(v / n, 1) for c, v in agg[k].items()})
+json.dump(summary, open("$R/gpurun_out/pmc_summary.json", "w"), indent=1, sort_keys=True)
+for k, v in summary.items():
+    if "k_search" in k and "FETCH_SIZE_per_launch" in v and "WRITE_SIZE_per_launch" in v:
+        json.dump({"kernel": k, "FETCH_SIZE_KB_per_launch": v["FETCH_SIZE_per_launch"],
+                   "WRITE_SIZE_KB_per_launch": v["WRITE_SIZE_per_launch"],
+                   "launches": v.get("launches_fetch"),
+                   "command": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate runs) -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline"},
+                  open("$R/gpurun_out/pmc_search_latest.json", "w"), indent=1)
 PY
