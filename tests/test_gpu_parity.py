@@ -2,6 +2,8 @@
 same seeded inputs.  Bar: bit-exact -- identical (target, source) per iteration, identical fp64
 cost and confidence, identical output bytes.  (The oracle itself is "parity unpinned" with
 respect to the reference; see oracle/cv2_restated.py.)"""
+import os
+
 import numpy as np
 import pytest
 
@@ -366,6 +368,46 @@ def test_device_mask_recipe_and_inpaint_image():
     assert np.array_equal(msk[0], pipeline_mask(small, dilation_size=4))
     assert np.array_equal(g["mask"], pipeline_mask(img, dilation_size=4))
     assert np.array_equal(inpaint_image(img, patch_size=9, dilation_size=4), g["out"])
+
+
+def test_directory_driver_end_to_end(tmp_path):
+    """scripts/main.py:36-60 loop shape: real JPEG files in, same-named JPEG files out; what is
+    encoded is, image for image, the oracle's result on the decoded pixels with the mask recipe of
+    src/utils.py:79-100."""
+    from PIL import Image
+    from helpers import pipeline_mask
+    import crim_batch_driver as drv
+    src, dst = tmp_path / "in", tmp_path / "out"
+    src.mkdir()
+    rng = np.random.default_rng(77)
+    shapes = [(64, 80), (64, 80), (64, 80), (72, 72), (64, 80)]
+    for i, (h, w) in enumerate(shapes):
+        img = crim_synth.xray_like(h, w, 900 + i, colour=(i % 2 == 0))
+        img = np.maximum(img, 40)                      # nothing dark by accident
+        y0, x0 = int(rng.integers(14, h - 30)), int(rng.integers(14, w - 30))
+        img[y0:y0 + 12, x0:x0 + 9] = 0                 # the missing region
+        Image.fromarray(img[:, :, ::-1]).save(src / ("im%03d.jpg" % i), quality=98)
+    (src / "readme.txt").write_text("not an image")
+    (src / "bad.jpg").write_bytes(b"not a jpeg")
+    captured = {}
+
+    def writer(path, bgr):
+        captured[os.path.basename(path)] = bgr.copy()
+        drv.write_bgr(path, bgr)
+
+    msgs = []
+    st = drv.inpaint_directory(str(src), str(dst), patch_size=9, dilation_size=4, batch=2,
+                               io_threads=3, log=msgs.append, writer=writer)
+    assert st["images"] == 5 and st["failed"] == 1 and msgs == ["bad.jpg failed to load."]
+    assert sorted(os.listdir(dst)) == ["im%03d.jpg" % i for i in range(5)]
+    for i in range(5):
+        name = "im%03d.jpg" % i
+        dec = drv.read_bgr(str(src / name))
+        m = pipeline_mask(dec, dilation_size=4)
+        assert m.sum() > 0
+        oout, _, _, _, _ = c_oracle.run(dec, m, 9, want_trace=False)
+        assert np.array_equal(captured[name], oout), name
+        assert drv.read_bgr(str(dst / name)).shape == dec.shape
 
 
 @pytest.mark.parametrize("nparts", [2, 3, 8])
