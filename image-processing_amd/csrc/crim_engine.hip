@@ -222,7 +222,9 @@ static void launch_search(const Params& pin, hipStream_t s, int sy0 = 0, int row
     }
     if (!p.dot4) {
         // SB_H == MS_ROWS: the block rows of both specialised kernels coincide
-        dim3 mgrid((std::max(p.W - p.half, 1) + MS_W - 1) / MS_W, rows, p.B);
+        p.mgx = (std::max(p.W - p.half, 1) + MS_W - 1) / MS_W;
+        p.mrows = rows;
+        dim3 mgrid((unsigned)p.mgx * rows * p.B);
         switch (p.P) {
             case 3: if (p.chroma) hipLaunchKernelGGL((k_search_mfma<3, true>), mgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_mfma<3, false>), mgrid, block, 0, s, p); return;
             case 5: if (p.chroma) hipLaunchKernelGGL((k_search_mfma<5, true>), mgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_mfma<5, false>), mgrid, block, 0, s, p); return;
@@ -259,7 +261,7 @@ static size_t priority_lds_bytes(const Params& p) {
 }
 
 static void launch_priority(const Params& p, hipStream_t s) {
-    const dim3 grid(p.pgrid, p.B), block(64);
+    const dim3 grid((unsigned)p.pgrid * p.B), block(64);
     const size_t lds = priority_lds_bytes(p);
     switch (p.P) {
         case 3: hipLaunchKernelGGL(k_priority<3>, grid, block, lds, s, p); break;

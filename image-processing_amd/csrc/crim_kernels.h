@@ -42,6 +42,21 @@ __device__ __forceinline__ const_u32_ptr as_const_u32(const void* p) {
     return (const_u32_ptr)(uintptr_t)p;
 }
 
+// Workgroups are handed to the 8 XCDs round-robin by linear id.  A 1-D grid of `per_image` blocks
+// for each of `nimg` images is decoded so that every block of image i runs on XCD i % 8 (its L2
+// then serves what the blocks of one image share: overlapping tile rows, halos, descriptors).
+// Falls back to image-major order when the image count is not a multiple of 8.
+__device__ __forceinline__ void xcd_decode(unsigned id, int per_image, int nimg, int* img, int* sub) {
+    if ((nimg & 7) == 0) {
+        const unsigned r = id & 7u, q = id >> 3;
+        *sub = (int)(q % (unsigned)per_image);
+        *img = (int)(8u * (q / (unsigned)per_image) + r);
+    } else {
+        *sub = (int)(id % (unsigned)per_image);
+        *img = (int)(id / (unsigned)per_image);
+    }
+}
+
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 
@@ -430,7 +445,9 @@ __device__ __forceinline__ FrontEval finish_front_pixel(double cnew, const int n
 template <int PT>
 __global__ __launch_bounds__(64) void k_priority(Params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int b = p.b0 + blockIdx.y;
+    int img_, bx;
+    xcd_decode(blockIdx.x, p.pgrid, p.B, &img_, &bx);
+    const int b = p.b0 + img_;
     ImgState* st = p.st + b;
     STAMP(0);
     if (!st->live) return;
@@ -438,7 +455,7 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
     const size_t HW = (size_t)H * W;
     const int nt = (int)st->tcount;
     STAMP(1);
-    if ((int)blockIdx.x >= nt) return;
+    if (bx >= nt) return;
     const int RS = PT > 0 ? CRIM_TILE + PT - 1 : CRIM_TILE + 2 * half;   // edge of the staged region
     constexpr int MS = CRIM_TILE + 2;                                    // edge of the staged mask
     uint4* s_el = (uint4*)smem;
@@ -473,7 +490,7 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
     const int rpp = 64 >> sh;
     const int scol = lane & ((1 << sh) - 1), srow = lane >> sh;
 
-    for (int ti = blockIdx.x; ti < nt; ti += gridDim.x) {
+    for (int ti = bx; ti < nt; ti += p.pgrid) {
         const int tile = tl[ti];
         if (tf[tile] <= 0) continue;              // block-uniform
         const int tY = tile / p.tnx, tX = tile - tY * p.tnx;
@@ -1087,11 +1104,14 @@ void k_search_mfma(Params p) {
     __shared__ unsigned s_i[4];
     __shared__ int s_bound;
 
-    const int b = p.b0 + blockIdx.z;
+    int img_, tile_;
+    xcd_decode(blockIdx.x, p.mgx * p.mrows, p.B, &img_, &tile_);
+    const int b = p.b0 + img_;
     const Desc* __restrict__ d = p.desc + b;
     if (!d->live) return;
     const int ncy = d->ncy, ncx = d->ncx;
-    const int y0 = (p.sy0 + blockIdx.y) * MS_ROWS, x0 = blockIdx.x * MS_W;
+    const int tby = tile_ / p.mgx, tbx = tile_ - tby * p.mgx;
+    const int y0 = (p.sy0 + tby) * MS_ROWS, x0 = tbx * MS_W;
     if (y0 >= ncy || x0 >= ncx) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     STAMP(32);
