@@ -332,7 +332,7 @@ extern "C" void crim_destroy(crim_t* h) {
         if (ln.stream) (void)hipStreamDestroy(ln.stream);
     for (auto e : h->ev) (void)hipEventDestroy(e);
     Params& p = h->prm;
-    void* bufs[] = {p.bgr, p.planes, p.mask, p.grey, p.grad, p.conf, p.invalid, p.tfront, p.tlist, p.st,
+    void* bufs[] = {p.bgr, p.planes, p.mask, p.grey, p.grad, p.conf, p.invalid, p.invbits, p.tfront, p.tlist, p.st,
                     p.desc, p.plist, p.slist, p.xchg, p.trace, p.dbg, h->d_gamma, h->d_cbrt, h->d_peek};
     for (void* q : bufs)
         if (q) (void)hipFree(q);
@@ -368,6 +368,7 @@ extern "C" int crim_create_batch(int batch, int H, int W, int patch_size, int de
     p.ND = (p.P + 6) / 4;
     p.Wp = round_up(W + 16, 16);
     p.Wi = round_up(W, 4) + 4;
+    p.Wb = 4 * ((W + MS_W - 1) / MS_W);
     p.tnx = (W + CRIM_TILE - 1) / CRIM_TILE;
     p.tny = (H + CRIM_TILE - 1) / CRIM_TILE;
     // the candidate grid is largest for the most clipped patch: (H - half) x (W - half)
@@ -390,6 +391,7 @@ extern "C" int crim_create_batch(int batch, int H, int W, int patch_size, int de
     alloc((void**)&p.grad, Bz * HW * sizeof(int));
     alloc((void**)&p.conf, Bz * 2 * HW * sizeof(double));
     alloc((void**)&p.invalid, Bz * H * p.Wi);
+    alloc((void**)&p.invbits, Bz * H * p.Wb * sizeof(unsigned long long));
     p.tcap = 2 * p.tnx * p.tny;
     alloc((void**)&p.tfront, Bz * p.tnx * p.tny * sizeof(int));
     alloc((void**)&p.tlist, Bz * p.tcap * sizeof(int));
@@ -409,6 +411,7 @@ extern "C" int crim_create_batch(int batch, int H, int W, int patch_size, int de
     if (e == hipSuccess) e = hipMemcpy(h->d_cbrt, t.cbrt_, sizeof(t.cbrt_), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(p.planes, 0, Bz * CRIM_NPL * H * p.Wp);
     if (e == hipSuccess) e = hipMemset(p.invalid, 1, Bz * H * p.Wi);
+    if (e == hipSuccess) e = hipMemset(p.invbits, 0xff, Bz * H * p.Wb * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(p.st, 0, Bz * sizeof(ImgState));
     if (e == hipSuccess) e = hipMemset(p.dbg, 0, 64 * sizeof(long long));
     if (e == hipSuccess) e = hipMemset(p.desc, 0, Bz * sizeof(Desc));

@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) void k_init_fields(Params p, int first) {
     const int x = blockIdx.x * CRIM_TILE + (threadIdx.x & 15);
     const size_t HW = (size_t)p.H * p.W;
     const uint8_t* mk = p.mask + b * HW;
-    int isfront = 0;
+    int isfront = 0, inv_bit = 1;
     if (y < p.H && x < p.W) {
         p.grad[b * HW + (size_t)y * p.W + x] = grad_packed(p.grey + b * HW, mk, p.H, p.W, y, x);
         int inv = 1;
@@ -356,8 +356,18 @@ __global__ __launch_bounds__(256) void k_init_fields(Params p, int first) {
                     if (mk[(size_t)(y + i) * p.W + x + j]) { inv = 1; break; }
         }
         p.invalid[((size_t)b * p.H + y) * p.Wi + x] = (uint8_t)inv;
+        inv_bit = inv;
         int nb[9];
         isfront = front_weight(mk, p.H, p.W, y, x, nb) > 0;
+    }
+    {
+        // bitmap form: a wave covers 4 tile rows of 16 origins; origins beyond the image stay 1
+        const unsigned long long bal = __ballot(inv_bit);
+        const int lane = threadIdx.x & 63;
+        if ((lane & 15) == 0 && y < p.H) {
+            unsigned short* row = (unsigned short*)(p.invbits + ((size_t)b * p.H + y) * p.Wb);
+            row[blockIdx.x] = (unsigned short)(bal >> (lane & 48));
+        }
     }
     const int cnt = __syncthreads_count(isfront);
     if (threadIdx.x == 0) {
@@ -1132,15 +1142,13 @@ void k_search_mfma(Params p) {
     // ---- every global load of the prologue is issued before the first is used: window validity
     // bytes (addresses clamped into the map, range test applied afterwards), template fragments
     // plane chunks.
-    uint8_t iv[R][4];
+    unsigned long long ivw[R];
     if (!clipped) {
+        // one 64-bit word per origin row holds this lane's four windows (bits 16j + (lane & 15));
+        // origins beyond the candidate grid are marked in the map itself
+        const unsigned long long* ib = p.invbits + (size_t)b * H * p.Wb + (x0 >> 6) + (lane >> 4);
 #pragma unroll
-        for (int yy = 0; yy < R; ++yy)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int y = imin(wy + yy, ncy - 1), x = imin(wx + 16 * j, ncx - 1);
-                iv[yy][j] = inv[(size_t)y * p.Wi + x];
-            }
+        for (int yy = 0; yy < R; ++yy) ivw[yy] = ib[(size_t)imin(wy + yy, H - 1) * p.Wb];
     }
     // template rows: one 16-byte chunk per thread, the zero padding by the same threads
     constexpr int NZ = (NCC + 1) * 2 * NS;
@@ -1183,9 +1191,9 @@ void k_search_mfma(Params p) {
         for (int yy = 0; yy < R; ++yy)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int bad = (wy + yy >= ncy || wx + 16 * j >= ncx) ? 1 : (int)iv[yy][j];
-                acc[yy][j] = bad ? POISON : 0;
-                anyvalid |= !bad;
+                const int bad = (int)((uint32_t)(ivw[yy] >> (16 * j + (lane & 15))) & 1u);
+                acc[yy][j] = bad << 20;
+                anyvalid |= bad ^ 1;
             }
     } else {
         for (int yy = 0; yy < R; ++yy)
@@ -1587,19 +1595,39 @@ __global__ __launch_bounds__(256) void k_update(Params p) {
         s_rw[i][0] = lo; s_rw[i][1] = hi;
     }
     __syncthreads();
-    for (int e = tid; e < oh * ow; e += 256) {
-        const int i = e / ow, j = e - i * ow;
-        const int oy = r0 - (P - 1) + i, ox = c0 - (P - 1) + j;
-        if (oy < 0 || ox < 0 || oy > H - P || ox > W - P) continue;
-        // bits [og + j, og + j + P) of the 128-bit row window
-        const int sft = og + j;
-        const unsigned long long lo = s_rw[i][0], hi = s_rw[i][1];
-        unsigned long long w;
-        if (sft == 0) w = lo;
-        else if (sft < 64) w = (lo >> sft) | (hi << (64 - sft));
-        else w = hi >> (sft - 64);
-        const unsigned long long pm = (1ull << P) - 1ull;
-        inv[(size_t)oy * p.Wi + ox] = (uint8_t)((w & pm) != 0);
+    // One wave per origin row, one lane per origin (ow <= 2P-1 <= 61): the byte map is stored, the
+    // bitmap cleared with fire-and-forget atomics (a window only ever turns admissible).
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        unsigned long long* ib = p.invbits + (size_t)b * H * p.Wb;
+        for (int i = wave; i < oh; i += 4) {
+            const int oy = r0 - (P - 1) + i, ox = c0 - (P - 1) + lane;
+            const bool in = lane < ow && oy >= 0 && ox >= 0 && oy <= H - P && ox <= W - P;
+            bool bad = true;
+            if (in) {
+                // bits [og + lane, og + lane + P) of the 128-bit row window
+                const int sft = og + lane;
+                const unsigned long long lo = s_rw[i][0], hi = s_rw[i][1];
+                unsigned long long w;
+                if (sft == 0) w = lo;
+                else if (sft < 64) w = (lo >> sft) | (hi << (64 - sft));
+                else w = hi >> (sft - 64);
+                const unsigned long long pm = (1ull << P) - 1ull;
+                bad = (w & pm) != 0;
+                inv[(size_t)oy * p.Wi + ox] = (uint8_t)bad;
+            }
+            const unsigned long long good = __ballot(in && !bad);   // bit l: origin ox0 + l is admissible
+            if (good != 0 && lane < 2) {
+                // origins ox0 .. ox0+63 straddle at most two 64-bit words
+                const int ox0 = c0 - (P - 1);
+                const int wi = (ox0 >> 6) + lane;          // arithmetic shift: floor for negative ox0
+                const int sh = ox0 & 63;
+                unsigned long long clr;
+                if (lane == 0) clr = good << sh;
+                else clr = sh ? good >> (64 - sh) : 0ull;
+                if (clr != 0 && wi >= 0 && wi < p.Wb) atomicAnd(ib + (size_t)oy * p.Wb + wi, ~clr);
+            }
+        }
     }
     // ---- per-tile front counts: only pixels within one pixel of the patch can join the front
     // (a filled pixel next to still-masked ones) or leave it (its masked diagonal neighbours

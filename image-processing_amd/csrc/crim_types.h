@@ -90,6 +90,7 @@ struct Params {
     int ND;       // dwords per shifted template row
     int Wp;       // pitch of the search byte planes
     int Wi;       // pitch of the window-validity map
+    int Wb;       // 64-bit words per row of the window-validity bitmap
     int tnx, tny; // 16x16 tile grid over the whole image (upload-time kernels)
     int snx, sny; // search block grid
     int sy0;      // first block row a search launch covers (split search; 0 otherwise)
@@ -108,6 +109,7 @@ struct Params {
     int* grad;         // [B][H][W] packed (int16 2*gy, int16 2*gx)
     double* conf;      // [B][2][H][W]
     uint8_t* invalid;  // [B][H][Wi] 1: the P x P window at this origin holds a masked pixel
+    unsigned long long* invbits;  // [B][H][Wb] the same map, one bit per origin (bit x%64 of word x/64)
     ImgState* st;
     Desc* desc;
     int tcap;          // capacity of one image's tile list (twice the tile count)
