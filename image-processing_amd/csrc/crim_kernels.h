@@ -17,8 +17,15 @@
         if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)      \
             p.dbg[slot] = wall_clock64();                                                   \
     } while (0)
+// the same for a block in the middle of a 1-D grid (steady state: warm instruction cache, loaded GPU)
+#define STAMP_MID(slot)                                                                     \
+    do {                                                                                    \
+        if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2 + 5)                            \
+            p.dbg[slot] = wall_clock64();                                                   \
+    } while (0)
 #else
 #define STAMP(slot) do {} while (0)
+#define STAMP_MID(slot) do {} while (0)
 #endif
 
 // ------------------------------------------------------------------------------------------
@@ -405,16 +412,27 @@ __global__ __launch_bounds__(256) void k_tiles(Params p) {
     const int b = p.b0 + blockIdx.x;
     ImgState* st = p.st + b;
     if (!st->live) return;
-    __shared__ unsigned s_n;
-    if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
+    // Ordered compaction (row-major tile order): neighbouring list entries are neighbouring tiles,
+    // whose staged regions overlap, and the priority stage visits neighbouring entries together.
+    __shared__ unsigned s_w[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nt = p.tnx * p.tny;
     const int* tf = p.tfront + (size_t)b * nt;
     int* tl = p.tlist + (size_t)b * p.tcap;
-    for (int t = threadIdx.x; t < nt; t += 256)
-        if (tf[t] > 0) tl[atomicAdd(&s_n, 1u)] = t;
-    __syncthreads();
-    if (threadIdx.x == 0) st->tcount = s_n;
+    unsigned base = 0;
+    for (int t0 = 0; t0 < nt; t0 += 256) {
+        const int t = t0 + tid;
+        const bool on = t < nt && tf[t] > 0;
+        const unsigned long long bal = __ballot(on);
+        if (lane == 0) s_w[wv] = (unsigned)__popcll(bal);
+        __syncthreads();
+        unsigned off = base;
+        for (int w = 0; w < wv; ++w) off += s_w[w];
+        if (on) tl[off + __popcll(bal & ((1ull << lane) - 1ull))] = t;
+        base += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        __syncthreads();
+    }
+    if (tid == 0) st->tcount = base;
 }
 
 // Data term (criminisi_inpainter.py:129-214) and priority (:112) of a front pixel from its new
@@ -459,12 +477,12 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
     xcd_decode(blockIdx.x, p.pgrid, p.B, &img_, &bx);
     const int b = p.b0 + img_;
     ImgState* st = p.st + b;
-    STAMP(0);
+    STAMP_MID(0);
     if (!st->live) return;
     const int H = p.H, W = p.W, half = p.half;
     const size_t HW = (size_t)H * W;
     const int nt = (int)st->tcount;
-    STAMP(1);
+    STAMP_MID(1);
     if (bx >= nt) return;
     const int RS = PT > 0 ? CRIM_TILE + PT - 1 : CRIM_TILE + 2 * half;   // edge of the staged region
     constexpr int MS = CRIM_TILE + 2;                                    // edge of the staged mask
@@ -626,7 +644,7 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
         }
         __syncthreads();   // the staging buffers are reused by the next tile
     }
-    STAMP(2);
+    STAMP_MID(2);
     // wave arg-max: highest priority, lowest row-major index on ties (np.argmax, :217)
     for (int off_ = 32; off_ > 0; off_ >>= 1) {
         const double op = __shfl_down(bestP, off_);
@@ -639,7 +657,7 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
         e.prio = bestP; e.pos = bestI; e.pad = 0;
         p.plist[(size_t)b * p.pgrid + k] = e;
     }
-    STAMP(3);
+    STAMP_MID(3);
 }
 
 // Full-frame front / data / priority of the iteration that would run next (debug / parity
@@ -1124,7 +1142,7 @@ void k_search_mfma(Params p) {
     const int y0 = (p.sy0 + tby) * MS_ROWS, x0 = tbx * MS_W;
     if (y0 >= ncy || x0 >= ncx) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    STAMP(32);
+    STAMP_MID(32);
     if (tid == 0) s_bound = __hip_atomic_load(&p.st[b].bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int H = p.H, W = p.W;
     const size_t HW = (size_t)H * W;
@@ -1205,7 +1223,7 @@ void k_search_mfma(Params p) {
             }
     }
     if (!__syncthreads_or(anyvalid)) return;
-    STAMP(33);
+    STAMP_MID(33);
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) {
         if (s < NCC && !((chmask >> s) & 1)) continue;
@@ -1217,9 +1235,9 @@ void k_search_mfma(Params p) {
         uint4* z = (uint4*)&zl[0][0][0] + 3 * tid;
         z[0] = make_uint4(0, 0, 0, 0); z[1] = zv; z[2] = make_uint4(0, 0, 0, 0);
     }
-    STAMP(34);
+    STAMP_MID(34);
     __syncthreads();
-    STAMP(35);
+    STAMP_MID(35);
 
     if (__any(anyvalid)) {
         const int g = lane >> 4;
@@ -1270,7 +1288,7 @@ void k_search_mfma(Params p) {
         plane_pass(SLOT_L, Bk);
     }
 
-    STAMP(36);
+    STAMP_MID(36);
     // Same two-phase pricing as the vector kernel: a window's cost is at least its integer S.
     double bc = INFINITY;
     unsigned bi = 0xffffffffu;
@@ -1293,9 +1311,9 @@ void k_search_mfma(Params p) {
         const int ub = ubd < 2147483647.0 ? (int)ubd : 0x7fffffff;
         if (ub < gbound) atomicMin(&s_bound, ub);
     }
-    STAMP(37);
+    STAMP_MID(37);
     __syncthreads();
-    STAMP(38);
+    STAMP_MID(38);
     const int ub = s_bound;
     if (kidx >= 0) {
         const long long lim = (long long)ub - soff;
@@ -1321,10 +1339,10 @@ void k_search_mfma(Params p) {
                     }
         }
     }
-    STAMP(39);
+    STAMP_MID(39);
     if (tid == 0 && ub < gbound) atomicMin(&p.st[b].bound, ub);
     block_min_emit(p, b, bc, bi, s_c, s_i);
-    STAMP(40);
+    STAMP_MID(40);
 }
 
 // Unspecialised search for any patch edge: one origin at a time, planes read from global
