@@ -36,14 +36,28 @@ MFMA_I8_PEAK_TOPS = 5033.2         # 256 CU x 4 SIMD x 1024 MAC/clk x 2 op x 2.4
 HBM_PEAK_GBS = 8000.0              # HBM3E
 
 
-def make_batch(batch, rank):
+def _make_one(seed):
     import crim_synth
+    return (crim_synth.xray_like(H, W, seed, colour=False),
+            crim_synth.blob_mask(H, W, seed, fraction=MASK_FRACTION, margin=PATCH))
+
+
+def make_batch(batch, rank):
+    """Seeded synthetic images and masks (seed = 1000 * config + global image index), generated on
+    a few host processes (forked before this process touches the GPU)."""
+    import multiprocessing as mp
+    seeds = [1000 * CONFIG_ID + rank * batch + i for i in range(batch)]
     imgs = np.empty((batch, H, W, 3), np.uint8)
     masks = np.empty((batch, H, W), np.uint8)
-    for i in range(batch):
-        seed = 1000 * CONFIG_ID + rank * batch + i
-        imgs[i] = crim_synth.xray_like(H, W, seed, colour=False)
-        masks[i] = crim_synth.blob_mask(H, W, seed, fraction=MASK_FRACTION, margin=PATCH)
+    workers = max(1, min(16, os.cpu_count() or 1, batch // 32))
+    if workers > 1:
+        with mp.get_context("fork").Pool(workers) as pool:
+            res = pool.map(_make_one, seeds, chunksize=16)
+    else:
+        res = [_make_one(s) for s in seeds]
+    for i, (im, mk) in enumerate(res):
+        imgs[i] = im
+        masks[i] = mk
     return imgs, masks
 
 
@@ -170,7 +184,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "u8/int32 dot products, f64 priorities and costs",
+        "dtype": "i8",
         "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: 256x256 grey X-ray-like image, synthetic "
                                "10%% mask, patch_size 9; %d such images per GPU filled in lock "
