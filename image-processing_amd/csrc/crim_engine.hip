@@ -620,7 +620,7 @@ static int run_split(crim_engine* h, long max_iters) {
                 if (h->split_rank >= 0 && part != h->split_rank) continue;
                 const int y0 = (int)((long)p.sny * part / parts), y1 = (int)((long)p.sny * (part + 1) / parts);
                 launch_search(p, ln.stream, y0, y1 - y0);
-                hipLaunchKernelGGL(k_local_best, dim3(1), dim3(256), 0, ln.stream, p, part);
+                hipLaunchKernelGGL(k_local_best, dim3(1), dim3(256), 0, ln.stream, p, part, y0, y1 - y0);
             }
             if (h->split_rank >= 0) {
                 const ncclResult_t r = g_rccl.all_gather(p.xchg + h->split_rank, p.xchg, sizeof(SEntry),

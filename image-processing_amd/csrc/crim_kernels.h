@@ -880,7 +880,17 @@ __device__ __forceinline__ double cand_cost(const Desc* d, int S, int y, int x) 
     return (double)S + sqrt(dy * dy + dx * dx);
 }
 
-__device__ __forceinline__ void block_min_emit(const Params& p, int b, double bc, unsigned bi,
+// Every search block owns one slot of its image's partial list: block row * snx + block column of
+// the launch's tiling (rows are 32 origins for every kernel; the matrix-core kernel's 256-wide tiles
+// use the first columns).  A block without an admissible window stores an empty entry, so that
+// the consumers can read the slots of the blocks inside the candidate grid without a count.
+__device__ __forceinline__ void emit_empty(const Params& p, int b, int slot) {
+    SEntry e;
+    e.cost = INFINITY; e.idx = 0xffffffffu; e.pad = 0;
+    p.slist[(size_t)b * p.snx * p.sny + slot] = e;
+}
+
+__device__ __forceinline__ void block_min_emit(const Params& p, int b, int slot, double bc, unsigned bi,
                                                double* s_c, unsigned* s_i) {
     const int tid = threadIdx.x;
     for (int off = 32; off > 0; off >>= 1) {
@@ -893,13 +903,21 @@ __device__ __forceinline__ void block_min_emit(const Params& p, int b, double bc
     if (tid == 0) {
         for (int w = 1; w < 4; ++w)
             if (better_cost(s_c[w], s_i[w], bc, bi)) { bc = s_c[w]; bi = s_i[w]; }
-        if (bi != 0xffffffffu) {
-            const unsigned k = atomicAdd(&p.st[b].scount, 1u);
-            SEntry e;
-            e.cost = bc; e.idx = bi; e.pad = 0;
-            p.slist[(size_t)b * p.snx * p.sny + k] = e;
-        }
+        SEntry e;
+        e.cost = bc; e.idx = bi; e.pad = 0;
+        p.slist[(size_t)b * p.snx * p.sny + slot] = e;
     }
+}
+
+// Is entry i of an image's partial list the slot of a block inside the candidate grid (block
+// rows [row0, row1), `ncols` block columns of the active tiling)?
+__device__ __forceinline__ bool slot_in_grid(const Params& p, int i, int row0, int row1, int ncols) {
+    const int r = i / p.snx, c = i - r * p.snx;
+    return r >= row0 && r < row1 && c < ncols;
+}
+__device__ __forceinline__ int search_cols(const Params& p, int ncx) {
+    const int tw = (p.generic || p.dot4) ? SB_W : MS_W;
+    return (ncx + tw - 1) / tw;
 }
 
 // Specialised search: each thread scores 4 consecutive x origins (one dword of every byte
@@ -956,7 +974,11 @@ __global__ __launch_bounds__(256) void k_search(Params p) {
     }
     // (Compacting the live 4x4 origin groups so that they fill whole waves was measured: no gain,
     // 57 us vs 56 us per launch of 128 images with a 10 % mask.)
-    if (!__syncthreads_or(vbits != 0)) return;
+    const int slot = (p.sy0 + (int)blockIdx.y) * p.snx + (int)blockIdx.x;
+    if (!__syncthreads_or(vbits != 0)) {
+        if (tid == 0) emit_empty(p, b, slot);
+        return;
+    }
 
     // A Lab channel whose template k*(T-128) is zero everywhere adds nothing to the cross term
     // (a and b of every grey pixel are exactly 128), so its plane is neither staged nor scored.
@@ -1089,7 +1111,7 @@ __global__ __launch_bounds__(256) void k_search(Params p) {
                 }
     }
     if (tid == 0 && ub < gbound) atomicMin(&p.st[b].bound, ub);
-    block_min_emit(p, b, bc, bi, s_c, s_i);
+    block_min_emit(p, b, slot, bc, bi, s_c, s_i);
 }
 
 // Matrix-core search.  For one template row t[0..P) and 16 x shifts n, the 32 x 16 matrix
@@ -1222,7 +1244,11 @@ void k_search_mfma(Params p) {
                 anyvalid |= ok;
             }
     }
-    if (!__syncthreads_or(anyvalid)) return;
+    const int slot = (p.sy0 + tby) * p.snx + tbx;
+    if (!__syncthreads_or(anyvalid)) {
+        if (tid == 0) emit_empty(p, b, slot);
+        return;
+    }
     STAMP_MID(33);
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) {
@@ -1341,7 +1367,7 @@ void k_search_mfma(Params p) {
     }
     STAMP_MID(39);
     if (tid == 0 && ub < gbound) atomicMin(&p.st[b].bound, ub);
-    block_min_emit(p, b, bc, bi, s_c, s_i);
+    block_min_emit(p, b, slot, bc, bi, s_c, s_i);
     STAMP_MID(40);
 }
 
@@ -1388,25 +1414,28 @@ __global__ __launch_bounds__(256) void k_search_generic(Params p) {
             if (better_cost(c, idx, bc, bi)) { bc = c; bi = idx; }
         }
     }
-    block_min_emit(p, b, bc, bi, s_c, s_i);
+    block_min_emit(p, b, (p.sy0 + (int)blockIdx.y) * p.snx + (int)blockIdx.x, bc, bi, s_c, s_i);
 }
 
 // Split search (one image, the window-origin rows divided into parts that different launches --
 // on one GPU or on several -- score): folds the partial list of the part just searched into
 // slot `part` of the exchange array and empties the list for the next part.  Every process then
 // holds all slots (directly, or after an all-gather) and k_update reduces them.
-__global__ __launch_bounds__(256) void k_local_best(Params p, int part) {
+__global__ __launch_bounds__(256) void k_local_best(Params p, int part, int row0, int nrows) {
     const int b = p.b0;
     ImgState* st = p.st + b;
     if (!st->live) return;
     __shared__ double s_c[4];
     __shared__ unsigned s_i[4];
     const int tid = threadIdx.x;
-    const unsigned n = st->scount;
+    const Desc* d = p.desc + b;
     const SEntry* sl = p.slist + (size_t)b * p.snx * p.sny;
+    const int grows = (d->ncy + SB_H - 1) / SB_H, gcols = search_cols(p, d->ncx);
+    const int row1 = row0 + nrows < grows ? row0 + nrows : grows;
     double bc = INFINITY;
     unsigned bi = 0xffffffffu;
-    for (unsigned i = tid; i < n; i += 256) {
+    for (int i = row0 * p.snx + tid; i < row1 * p.snx; i += 256) {
+        if (!slot_in_grid(p, i, row0, row1, gcols)) continue;
         const SEntry e = sl[i];
         if (better_cost(e.cost, e.idx, bc, bi)) { bc = e.cost; bi = e.idx; }
     }
@@ -1423,7 +1452,6 @@ __global__ __launch_bounds__(256) void k_local_best(Params p, int part) {
         SEntry e;
         e.cost = bc; e.idx = bi; e.pad = 0;
         p.xchg[part] = e;
-        st->scount = 0;
     }
 }
 
@@ -1468,10 +1496,15 @@ __global__ __launch_bounds__(256) void k_update(Params p) {
         if (i < cap) spec[k] = sl[i];
     }
     const int live = st->live;
-    const unsigned n = p.nparts > 0 ? (unsigned)p.nparts : st->scount;
     // loop state is read once, up front: thread 0 rewrites it at the end of this kernel
     const int cur = st->cur;
     const int ncx = d->ncx;
+    // entries to reduce: the exchange slots of a split search, else the slots of the search blocks
+    // inside the candidate grid
+    const int grows = p.nparts > 0 ? 1 : (d->ncy + SB_H - 1) / SB_H;
+    const int gcols = p.nparts > 0 ? p.nparts : search_cols(p, ncx);
+    const int gstride = p.nparts > 0 ? p.nparts : p.snx;
+    const int n = grows * gstride;
     const int r0 = d->r0, c0 = d->c0, ph = d->ph, pw = d->pw;
     const double cnew = d->cnew;
     if (!live) return;
@@ -1525,11 +1558,14 @@ __global__ __launch_bounds__(256) void k_update(Params p) {
     double bc = INFINITY;
     unsigned bi = 0xffffffffu;
 #pragma unroll
-    for (int k = 0; k < NSPEC; ++k)
-        if ((unsigned)(tid + 256 * k) < n && better_cost(spec[k].cost, spec[k].idx, bc, bi)) {
+    for (int k = 0; k < NSPEC; ++k) {
+        const int i = tid + 256 * k;
+        if (i < n && i % gstride < gcols && better_cost(spec[k].cost, spec[k].idx, bc, bi)) {
             bc = spec[k].cost; bi = spec[k].idx;
         }
-    for (unsigned i = tid + 256 * NSPEC; i < n; i += 256) {
+    }
+    for (int i = tid + 256 * NSPEC; i < n; i += 256) {
+        if (i % gstride >= gcols) continue;
         const SEntry e = sl[i];
         if (better_cost(e.cost, e.idx, bc, bi)) { bc = e.cost; bi = e.idx; }
     }
