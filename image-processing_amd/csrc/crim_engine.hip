@@ -369,6 +369,7 @@ extern "C" int crim_create_batch(int batch, int H, int W, int patch_size, int de
     p.Wp = round_up(W + 16, 16);
     p.Wi = round_up(W, 4) + 4;
     p.Wb = 4 * ((W + MS_W - 1) / MS_W);
+    p.dmax = (int)std::ceil(std::sqrt((double)H * H + (double)W * W)) + 1;
     p.tnx = (W + CRIM_TILE - 1) / CRIM_TILE;
     p.tny = (H + CRIM_TILE - 1) / CRIM_TILE;
     // the candidate grid is largest for the most clipped patch: (H - half) x (W - half)

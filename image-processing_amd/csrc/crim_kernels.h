@@ -1227,14 +1227,19 @@ void k_search_mfma(Params p) {
     v4i acc[R];
     int anyvalid = 0;
     if (!clipped) {
+        // bit 16j of (word >> n) is window j of the row; bit 20 of the accumulator is the poison
+        uint32_t all = 0xffffffffu;
 #pragma unroll
-        for (int yy = 0; yy < R; ++yy)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int bad = (int)((uint32_t)(ivw[yy] >> (16 * j + (lane & 15))) & 1u);
-                acc[yy][j] = bad << 20;
-                anyvalid |= bad ^ 1;
-            }
+        for (int yy = 0; yy < R; ++yy) {
+            const unsigned long long t = ivw[yy] >> (lane & 15);
+            const uint32_t lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
+            acc[yy][0] = (int)((lo << 20) & 0x100000u);
+            acc[yy][1] = (int)((lo << 4) & 0x100000u);
+            acc[yy][2] = (int)((hi << 20) & 0x100000u);
+            acc[yy][3] = (int)((hi << 4) & 0x100000u);
+            all &= lo & hi;
+        }
+        anyvalid = (all & 0x10001u) != 0x10001u;
     } else {
         for (int yy = 0; yy < R; ++yy)
             for (int j = 0; j < 4; ++j) {
@@ -1315,59 +1320,67 @@ void k_search_mfma(Params p) {
     }
 
     STAMP_MID(36);
-    // Same two-phase pricing as the vector kernel: a window's cost is at least its integer S.
+    // Pricing.  A window's cost is its integer S plus a distance that is never negative and never
+    // more than dmax, so (lowest S of the block) + dmax + 1 bounds the minimum cost from above
+    // without pricing anything; the block shares it through LDS and with the other blocks of the
+    // image through a relaxed global word (a stale bound only prunes less).  Only windows whose S
+    // does not exceed the bound are priced (fp64 sqrt) -- usually one or two per block -- so no
+    // window that could reach or tie the minimum is skipped.
     double bc = INFINITY;
     unsigned bi = 0xffffffffu;
     const int soff = d->soff2;
-    int smin = 0x7fffffff, kidx = -1;
+    int tmin = 0x7fffffff;
     if (anyvalid) {
 #pragma unroll
         for (int yy = 0; yy < R; ++yy)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (acc[yy][j] < smin) { smin = acc[yy][j]; kidx = yy * 4 + j; }
-        if (smin >= (POISON << 7)) kidx = -1;
+            for (int j = 0; j < 4; ++j) tmin = imin(tmin, acc[yy][j]);
     }
+    int wmin = tmin;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) wmin = imin(wmin, __shfl_xor(wmin, off));
     const int gbound = s_bound;
-    if (kidx >= 0 && (long long)smin + soff <= (long long)gbound) {
-        const int y = wy + (kidx >> 2), x = wx + 16 * (kidx & 3);
-        bc = cand_cost(d, smin + soff, y, x);
-        bi = (unsigned)y * (unsigned)ncx + (unsigned)x;
-        const double ubd = floor(bc) + 1.0;
-        const int ub = ubd < 2147483647.0 ? (int)ubd : 0x7fffffff;
-        if (ub < gbound) atomicMin(&s_bound, ub);
+    if (lane == 0 && wmin < (POISON << 7)) {
+        const long long u = (long long)wmin + soff + p.dmax + 1;
+        if (u < (long long)gbound) atomicMin(&s_bound, (int)u);
     }
     STAMP_MID(37);
     __syncthreads();
     STAMP_MID(38);
     const int ub = s_bound;
-    if (kidx >= 0) {
-        const long long lim = (long long)ub - soff;
-        const int ublocal = lim > (long long)(POISON << 7) - 1 ? (POISON << 7) - 1 : (int)lim;
-        // which of the other windows can still reach the bound (usually none)
-        unsigned todo = 0;
+    const long long lim = (long long)ub - soff;
+    const int ublocal = lim > (long long)(POISON << 7) - 1 ? (POISON << 7) - 1 : (int)lim;
+    if (tmin <= ublocal) {
 #pragma unroll
         for (int yy = 0; yy < R; ++yy)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (acc[yy][j] <= ublocal) todo |= 1u << (yy * 4 + j);
-        todo &= ~(1u << kidx);
-        if (todo) {
-#pragma unroll
-            for (int yy = 0; yy < R; ++yy)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (todo & (1u << (yy * 4 + j))) {
-                        const int y = wy + yy, x = wx + 16 * j;
-                        const double c = cand_cost(d, acc[yy][j] + soff, y, x);
-                        const unsigned idx = (unsigned)y * (unsigned)ncx + (unsigned)x;
-                        if (better_cost(c, idx, bc, bi)) { bc = c; bi = idx; }
-                    }
-        }
+                if (acc[yy][j] <= ublocal) {
+                    const int y = wy + yy, x = wx + 16 * j;
+                    const double c = cand_cost(d, acc[yy][j] + soff, y, x);
+                    const unsigned idx = (unsigned)y * (unsigned)ncx + (unsigned)x;
+                    if (better_cost(c, idx, bc, bi)) { bc = c; bi = idx; }
+                }
     }
     STAMP_MID(39);
     if (tid == 0 && ub < gbound) atomicMin(&p.st[b].bound, ub);
-    block_min_emit(p, b, slot, bc, bi, s_c, s_i);
+    // waves without a priced window skip the shuffle reduction
+    if (__any(bi != 0xffffffffu)) {
+        for (int off = 32; off > 0; off >>= 1) {
+            const double oc = __shfl_down(bc, off);
+            const unsigned oi = __shfl_down(bi, off);
+            if (better_cost(oc, oi, bc, bi)) { bc = oc; bi = oi; }
+        }
+    }
+    if (lane == 0) { s_c[wv] = bc; s_i[wv] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (better_cost(s_c[w], s_i[w], bc, bi)) { bc = s_c[w]; bi = s_i[w]; }
+        SEntry e;
+        e.cost = bc; e.idx = bi; e.pad = 0;
+        p.slist[(size_t)b * p.snx * p.sny + slot] = e;
+    }
     STAMP_MID(40);
 }
 
