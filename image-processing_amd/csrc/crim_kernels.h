@@ -277,9 +277,10 @@ __device__ __forceinline__ void lab_planes(const Params& p, int B_, int G_, int 
     out[2] = (uint8_t)(int8_t)bb;
     out[3] = (uint8_t)(Q % 255);
     out[4] = (uint8_t)(Q / 255);
-    // Q <= 3 * 128^2 = 49152; Q - 24576 = 256*h + l with l in [-128,127], h in [-96,96]: both
-    // fit the signed bytes the i8 matrix cores take.
-    const int Qc = Q - 24576;
+    // Q <= 3 * 128^2 = 49152; 24576 - Q = 256*h + l with l in [-128,127], h in [-96,96]: both
+    // fit the signed bytes the i8 matrix cores take.  (The negated quantity is stored so that the
+    // matrix-core search accumulates -S with nothing but left shifts between its passes.)
+    const int Qc = 24576 - Q;
     const int h = (Qc + 128) >> 8;
     out[5] = (uint8_t)(int8_t)(Qc - 256 * h);
     out[6] = (uint8_t)(int8_t)h;
@@ -1122,9 +1123,11 @@ __global__ __launch_bounds__(256) void k_search(Params p) {
 // row; the image fragment of rows (r, r+1) serves every (origin row y, step s) with y + 2s = r,
 // so each fragment is read from LDS once and used up to (P+1)/2 times.
 // Exact integer arithmetic: signed bytes, int32 accumulators.
-//   S_reference = 256 * sum k*h + sum k*l - 2 * sum_ch sum (Lab_ch-128) * k*(T_ch-128) + soff2
-// is built in ONE accumulator: the h-digit plane first, times -128, plus the cross terms, times -2,
-// plus the l-digit plane.  Inadmissible windows start from 2^20, i.e. end 2^28 too high.
+// With the stored digits 24576 - Q = 256*h + l,
+//   -S_reference = 256 * sum k*h + 2 * sum_ch sum (Lab_ch-128) * k*(T_ch-128) + sum k*l - soff2
+// is built in ONE accumulator with nothing but left shifts between the passes: the h-digit plane
+// first, << 7, plus the cross terms, << 1, plus the l-digit plane; the search then looks for the
+// LARGEST accumulator.  Inadmissible windows start from -2^20, i.e. end 2^28 too low.
 typedef int v4i __attribute__((ext_vector_type(4)));
 #ifndef MS_WPE
 #define MS_WPE(P, CHROMA) (((CHROMA) || (P) > 11) ? 2 : ((P) > 9 ? 3 : 4))
@@ -1227,16 +1230,17 @@ void k_search_mfma(Params p) {
     v4i acc[R];
     int anyvalid = 0;
     if (!clipped) {
-        // bit 16j of (word >> n) is window j of the row; bit 20 of the accumulator is the poison
+        // bit 16j of (word >> n) is window j of the row; an inadmissible window starts at -2^20
         uint32_t all = 0xffffffffu;
 #pragma unroll
         for (int yy = 0; yy < R; ++yy) {
             const unsigned long long t = ivw[yy] >> (lane & 15);
             const uint32_t lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
-            acc[yy][0] = (int)((lo << 20) & 0x100000u);
-            acc[yy][1] = (int)((lo << 4) & 0x100000u);
-            acc[yy][2] = (int)((hi << 20) & 0x100000u);
-            acc[yy][3] = (int)((hi << 4) & 0x100000u);
+            // one-bit signed field (0 or -1), times 2^20
+            acc[yy][0] = __builtin_amdgcn_sbfe((int)lo, 0, 1) << 20;
+            acc[yy][1] = __builtin_amdgcn_sbfe((int)lo, 16, 1) << 20;
+            acc[yy][2] = __builtin_amdgcn_sbfe((int)hi, 0, 1) << 20;
+            acc[yy][3] = __builtin_amdgcn_sbfe((int)hi, 16, 1) << 20;
             all &= lo & hi;
         }
         anyvalid = (all & 0x10001u) != 0x10001u;
@@ -1245,7 +1249,7 @@ void k_search_mfma(Params p) {
             for (int j = 0; j < 4; ++j) {
                 const int y = wy + yy, x = wx + 16 * j;
                 const int ok = (y < ncy && x < ncx && window_valid(p, d, inv, mask, y, x)) ? 1 : 0;
-                acc[yy][j] = ok ? 0 : POISON;
+                acc[yy][j] = ok ? 0 : -POISON;
                 anyvalid |= ok;
             }
     }
@@ -1310,12 +1314,12 @@ void k_search_mfma(Params p) {
         };
         plane_pass(SLOT_H, Bk);
 #pragma unroll
-        for (int yy = 0; yy < R; ++yy) acc[yy] *= -128;
+        for (int yy = 0; yy < R; ++yy) acc[yy] <<= 7;
 #pragma unroll
         for (int t = 0; t < NCC; ++t)
             if ((chmask >> t) & 1) plane_pass(t, Bc[t]);
 #pragma unroll
-        for (int yy = 0; yy < R; ++yy) acc[yy] *= -2;
+        for (int yy = 0; yy < R; ++yy) acc[yy] <<= 1;
         plane_pass(SLOT_L, Bk);
     }
 
@@ -1328,36 +1332,37 @@ void k_search_mfma(Params p) {
     // window that could reach or tie the minimum is skipped.
     double bc = INFINITY;
     unsigned bi = 0xffffffffu;
-    const int soff = d->soff2;
-    int tmin = 0x7fffffff;
+    const int soff = d->soff2;            // S_reference = soff - accumulator
+    int tmax = -0x7fffffff;
     if (anyvalid) {
 #pragma unroll
         for (int yy = 0; yy < R; ++yy)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) tmin = imin(tmin, acc[yy][j]);
+            for (int j = 0; j < 4; ++j) tmax = imax(tmax, acc[yy][j]);
     }
-    int wmin = tmin;
+    int wmax = tmax;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) wmin = imin(wmin, __shfl_xor(wmin, off));
+    for (int off = 32; off > 0; off >>= 1) wmax = imax(wmax, __shfl_xor(wmax, off));
     const int gbound = s_bound;
-    if (lane == 0 && wmin < (POISON << 7)) {
-        const long long u = (long long)wmin + soff + p.dmax + 1;
+    if (lane == 0 && wmax > -(POISON << 7)) {
+        const long long u = (long long)soff - wmax + p.dmax + 1;
         if (u < (long long)gbound) atomicMin(&s_bound, (int)u);
     }
     STAMP_MID(37);
     __syncthreads();
     STAMP_MID(38);
     const int ub = s_bound;
-    const long long lim = (long long)ub - soff;
-    const int ublocal = lim > (long long)(POISON << 7) - 1 ? (POISON << 7) - 1 : (int)lim;
-    if (tmin <= ublocal) {
+    // windows with S <= ub, i.e. accumulator >= soff - ub (never a poisoned one)
+    const long long lim = (long long)soff - ub;
+    const int thr = lim < -(long long)(POISON << 7) + 1 ? -(POISON << 7) + 1 : (int)lim;
+    if (tmax >= thr) {
 #pragma unroll
         for (int yy = 0; yy < R; ++yy)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (acc[yy][j] <= ublocal) {
+                if (acc[yy][j] >= thr) {
                     const int y = wy + yy, x = wx + 16 * j;
-                    const double c = cand_cost(d, acc[yy][j] + soff, y, x);
+                    const double c = cand_cost(d, soff - acc[yy][j], y, x);
                     const unsigned idx = (unsigned)y * (unsigned)ncx + (unsigned)x;
                     if (better_cost(c, idx, bc, bi)) { bc = c; bi = idx; }
                 }

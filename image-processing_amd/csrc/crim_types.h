@@ -62,7 +62,7 @@ struct Desc {
     int clipped;         // ph or pw smaller than the full patch edge
     int ncy, ncx;        // candidate grid: H-ph+1, W-pw+1
     int soff;            // S_reference = S_centred + soff
-    int soff2;           // S_reference = 256*sum k*h + sum k*l - 2*cross + soff2 (balanced Q digits)
+    int soff2;           // S_reference = soff2 - (256*sum k*h + 2*cross + sum k*l), digits of 24576 - Q
     int pad2;
     int rowmask;         // bit i set: template row i has at least one known pixel
     int chmask;          // bit c set: k * (Lab_c - 128) is nonzero somewhere in the template
@@ -104,7 +104,7 @@ struct Params {
     long trace_cap;
     uint8_t* bgr;      // [B][H][W][3]
     uint8_t* planes;   // [B][CRIM_NPL][H][Wp]  L-128, a-128, b-128 (int8), Q%255, Q/255 (uint8),
-                       // and the balanced digits l, h (int8) of Q - 24576 = 256*h + l
+                       // and the balanced digits l, h (int8) of 24576 - Q = 256*h + l
     uint8_t* mask;     // [B][H][W]
     uint8_t* grey;     // [B][H][W]
     int* grad;         // [B][H][W] packed (int16 2*gy, int16 2*gx)
