@@ -519,60 +519,65 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
     const int rpp = 64 >> sh;
     const int scol = lane & ((1 << sh) - 1), srow = lane >> sh;
 
+    // Rows of staging loads in flight per lane: the whole region when its edge is known at
+    // compile time, batches of 16 otherwise.
+    constexpr int NRB = PT > 0 ? (CRIM_TILE + PT - 1 + 1) / 2 : 16;
+    int tile_next = tl[bx];
     for (int ti = bx; ti < nt; ti += p.pgrid) {
-        const int tile = tl[ti];
-        if (tf[tile] <= 0) continue;              // block-uniform
+        const int tile = tile_next;
+        // Dependent round trips are what this kernel waits on, so independent loads travel
+        // together: the tile's front count (a stale list entry is dropped once it arrives), the
+        // next list entry, the mask and the confidence / gradient rows.
+        const int tfv = tf[tile];
+        if (ti + p.pgrid < nt) tile_next = tl[ti + p.pgrid];
         const int tY = tile / p.tnx, tX = tile - tY * p.tnx;
         const int ty0 = tY * CRIM_TILE, tx0 = tX * CRIM_TILE;
         const int ry0 = ty0 - half, rx0 = tx0 - half;
+        uint8_t mv[6];   // MS*MS = 324 <= 6*64
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int i = lane + 64 * k;
+            const int yy = imin(imax(ty0 - 1 + i / MS, -1), H), xx = imin(imax(tx0 - 1 + i % MS, -1), W);
+            mv[k] = mask[(size_t)reflect101(yy, H) * W + reflect101(xx, W)];
+        }
         // Pixels beyond the image are never read (patches are clipped to it): their records are
-        // filled from the clamped position.  Eight rows of loads are in flight per batch.
-        {
-            const int xx = imin(imax(rx0 + scol, 0), W - 1);
-            for (int rb = srow; rb < RS; rb += 8 * rpp) {
-                double cv[8];
-                int gv[8];
+        // filled from the clamped position.
+        const int xx = imin(imax(rx0 + scol, 0), W - 1);
+        bool first = true, stale = false;
+        for (int rb = srow; rb < RS; rb += NRB * rpp) {
+            double cv[NRB];
+            int gv[NRB];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int row = rb + k * rpp;
-                    cv[k] = 0.0; gv[k] = 0;
-                    if (row < RS && scol < RS) {
-                        const int yy = imin(imax(ry0 + row, 0), H - 1);
-                        const int idx = yy * W + xx;
-                        cv[k] = ccur[idx];
-                        gv[k] = grad[idx];
-                    }
+            for (int k = 0; k < NRB; ++k) {
+                const int row = imin(rb + k * rpp, RS - 1);
+                const int yy = imin(imax(ry0 + row, 0), H - 1);
+                const int idx = yy * W + xx;
+                cv[k] = ccur[idx];
+                gv[k] = grad[idx];
+            }
+            if (first) {
+                first = false;
+                if (tfv <= 0) { stale = true; break; }   // block-uniform
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const int i = lane + 64 * k;
+                    if (i < MS * MS) s_mask[i] = mv[k];
                 }
+            }
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int row = rb + k * rpp;
-                    if (row < RS && scol < RS) {
-                        const int gy2 = (int)(short)(gv[k] & 0xffff), gx2 = gv[k] >> 16;
-                        uint4 el;
-                        el.x = (uint32_t)__double2loint(cv[k]); el.y = (uint32_t)__double2hiint(cv[k]);
-                        el.z = (uint32_t)(gy2 * gy2 + gx2 * gx2) << 10;
-                        el.w = (uint32_t)gv[k];
-                        s_el[row * RS + scol] = el;
-                    }
+            for (int k = 0; k < NRB; ++k) {
+                const int row = rb + k * rpp;
+                if (row < RS && scol < RS) {
+                    const int gy2 = (int)(short)(gv[k] & 0xffff), gx2 = gv[k] >> 16;
+                    uint4 el;
+                    el.x = (uint32_t)__double2loint(cv[k]); el.y = (uint32_t)__double2hiint(cv[k]);
+                    el.z = (uint32_t)(gy2 * gy2 + gx2 * gx2) << 10;
+                    el.w = (uint32_t)gv[k];
+                    s_el[row * RS + scol] = el;
                 }
             }
         }
-        {
-            uint8_t mv[6];   // MS*MS = 324 <= 6*64
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                const int i = lane + 64 * k;
-                const int yy = ty0 - 1 + i / MS, xx = tx0 - 1 + i % MS;
-                mv[k] = 0;
-                if (i < MS * MS && yy >= -1 && yy <= H && xx >= -1 && xx <= W)
-                    mv[k] = mask[(size_t)reflect101(yy, H) * W + reflect101(xx, W)];
-            }
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                const int i = lane + 64 * k;
-                if (i < MS * MS) s_mask[i] = mv[k];
-            }
-        }
+        if (stale) continue;
         __syncthreads();
         int n = 0;
         for (int pass = 0; pass < CRIM_TILE * CRIM_TILE / 64; ++pass) {
@@ -607,7 +612,7 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
                 double r0 = 0.0, r1 = 0.0;
                 unsigned best = 0;
                 const unsigned kb = 1023u - 2u * (unsigned)l;
-#pragma unroll
+#pragma unroll 5
                 for (int i = 0; i < NE; ++i) {
                     const uint4 a = *(const uint4*)(eb + off[2 * i]);
                     const uint4 c = *(const uint4*)(eb + off[2 * i + 1]);
