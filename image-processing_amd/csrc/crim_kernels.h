@@ -771,71 +771,93 @@ __global__ __launch_bounds__(256) void k_select(Params p) {
     const uint8_t* mask = p.mask + b * HW;
     const uint8_t* planes = p.planes + (size_t)b * CRIM_NPL * H * p.Wp;
 
-    // the target's updated confidence is fetched alongside the patch
-    double cnew_t = 0.0;
-    if (tid == 0) cnew_t = p.conf[((size_t)b * 2 + (cur ^ 1)) * HW + pos];
+    // The target's updated confidence is fetched alongside the patch.  All loads are
+    // unconditional, from clamped positions, so that they travel together.
+    const double cnew_t = p.conf[((size_t)b * 2 + (cur ^ 1)) * HW + pos];
+    const bool mfma_path = P <= MS_PMAX && !p.dot4 && !p.generic;
+    constexpr int NEL = (CRIM_PMAX * CRIM_PMAX + 255) / 256;
+    int em[NEL], e0[NEL], e1[NEL], e2[NEL];
+#pragma unroll
+    for (int q = 0; q < NEL; ++q) {
+        const int e = imin(tid + 256 * q, P * P - 1);
+        const int i = e / P, j = e - i * P;
+        const int yy = imin(r0 + i, H - 1), xx = imin(c0 + j, W - 1);
+        em[q] = mask[(size_t)yy * W + xx];
+        const size_t o = (size_t)yy * p.Wp + xx;
+        e0[q] = (int8_t)planes[o];
+        e1[q] = (int8_t)planes[(size_t)H * p.Wp + o];
+        e2[q] = (int8_t)planes[(size_t)2 * H * p.Wp + o];
+    }
     int soff_local = 0, nk_local = 0;
-    for (int e = tid; e < P * P; e += 256) {
+#pragma unroll
+    for (int q = 0; q < NEL; ++q) {
+        const int e = tid + 256 * q;
+        if (e >= P * P) continue;
         const int i = e / P, j = e - i * P;
         int k = 0, t0 = 0, t1 = 0, t2 = 0;
-        if (i < ph && j < pw) {
-            const int yy = r0 + i, xx = c0 + j;
-            // mask and planes are loaded together; the planes are discarded under the mask
-            const int mv = mask[(size_t)yy * W + xx];
-            const size_t o = (size_t)yy * p.Wp + xx;
-            const int v0 = (int8_t)planes[o];
-            const int v1 = (int8_t)planes[(size_t)H * p.Wp + o];
-            const int v2 = (int8_t)planes[(size_t)2 * H * p.Wp + o];
-            k = 1 - mv;
-            if (k) {
-                t0 = v0; t1 = v1; t2 = v2;
-                // sum k*T~^2 - sum k*T^2 with T = T~ + 128
-                soff_local += -256 * (t0 + t1 + t2) - 3 * 16384;
-                ++nk_local;
-                atomicOr(&s_rowmask, 1 << i);
-                const int cm = (t0 ? 1 : 0) | (t1 ? 2 : 0) | (t2 ? 4 : 0);
-                if (cm) atomicOr(&s_chmask, cm);
-            }
+        if (i < ph && j < pw && !em[q]) {
+            k = 1;
+            t0 = e0[q]; t1 = e1[q]; t2 = e2[q];
+            // sum k*T~^2 - sum k*T^2 with T = T~ + 128
+            soff_local += -256 * (t0 + t1 + t2) - 3 * 16384;
+            ++nk_local;
+            atomicOr(&s_rowmask, 1 << i);
+            const int cm = (t0 ? 1 : 0) | (t1 ? 2 : 0) | (t2 ? 4 : 0);
+            if (cm) atomicOr(&s_chmask, cm);
         }
         s_k[e] = (uint8_t)k;
         s_t[0][e] = (int8_t)t0; s_t[1][e] = (int8_t)t1; s_t[2][e] = (int8_t)t2;
-        d->kflat[e] = (uint8_t)k;
-        d->tflat[0][e] = (int8_t)t0; d->tflat[1][e] = (int8_t)t1; d->tflat[2][e] = (int8_t)t2;
+        if (!mfma_path) {   // flat templates: read by the unspecialised search only
+            d->kflat[e] = (uint8_t)k;
+            d->tflat[0][e] = (int8_t)t0; d->tflat[1][e] = (int8_t)t1; d->tflat[2][e] = (int8_t)t2;
+        }
     }
     if (soff_local) atomicAdd(&s_soff, soff_local);
     if (nk_local) atomicAdd(&s_nk, nk_local);
     __syncthreads();
     STAMP(10);
 
-    // shifted template rows: dword j of shift s covers template columns 4j-s .. 4j-s+3
-    const int total = 5 * P * 4 * ND;
-    for (int e = tid; e < total; e += 256) {
-        const int j = e % ND;
-        const int s = (e / ND) & 3;
-        const int i = (e / (ND * 4)) % P;
-        const int type = e / (ND * 4 * P);
-        uint32_t v = 0;
-        for (int bb = 0; bb < 4; ++bb) {
-            const int col = 4 * j + bb - s;
-            uint32_t byte = 0;
-            if (col >= 0 && col < P) {
-                const int q = i * P + col;
-                if (type < 3) byte = (uint8_t)s_t[type][q];
-                else if (type == 3) byte = s_k[q];
-                else byte = s_k[q] ? 255u : 0u;
+    if (p.dot4) {
+        // shifted template rows of the vector search: dword j of shift s covers template columns
+        // 4j-s .. 4j-s+3
+        const int total = 5 * P * 4 * ND;
+        for (int e = tid; e < total; e += 256) {
+            const int j = e % ND;
+            const int s = (e / ND) & 3;
+            const int i = (e / (ND * 4)) % P;
+            const int type = e / (ND * 4 * P);
+            uint32_t v = 0;
+            for (int bb = 0; bb < 4; ++bb) {
+                const int col = 4 * j + bb - s;
+                uint32_t byte = 0;
+                if (col >= 0 && col < P) {
+                    const int q = i * P + col;
+                    if (type < 3) byte = (uint8_t)s_t[type][q];
+                    else if (type == 3) byte = s_k[q];
+                    else byte = s_k[q] ? 255u : 0u;
+                }
+                v |= byte << (8 * bb);
             }
-            v |= byte << (8 * bb);
+            d->tmpl[e] = v;
         }
-        d->tmpl[e] = v;
     }
-    // template rows of the matrix-core search, zero padded to 16 bytes
-    if (P <= MS_PMAX && !p.dot4 && !p.generic) {
+    // template rows of the matrix-core search, zero padded to 16 bytes: one row per thread
+    if (mfma_path) {
         const int rows = P + 1;
-        for (int e = tid; e < 4 * rows * 16; e += 256) {
-            const int col = e & 15, row = (e >> 4) % rows, type = (e >> 4) / rows;
-            uint8_t v = 0;
-            if (row < P && col < P) v = type < 3 ? (uint8_t)s_t[type][row * P + col] : s_k[row * P + col];
-            d->zrows[type][row][col] = v;
+        if (tid < 4 * rows) {
+            const int row = tid % rows, type = tid / rows;
+            unsigned long long lo = 0, hi = 0;
+            if (row < P) {
+                const uint8_t* src = type < 3 ? (const uint8_t*)&s_t[type][row * P] : &s_k[row * P];
+                for (int c = 0; c < P; ++c) {
+                    const unsigned long long byte = src[c];
+                    if (c < 8) lo |= byte << (8 * c);
+                    else hi |= byte << (8 * (c - 8));
+                }
+            }
+            uint4 o;
+            o.x = (uint32_t)lo; o.y = (uint32_t)(lo >> 32); o.z = (uint32_t)hi; o.w = (uint32_t)(hi >> 32);
+            *(uint4*)d->zrows[type][row] = o;
         }
     }
     if (tid == 0) {

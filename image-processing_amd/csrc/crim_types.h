@@ -78,7 +78,7 @@ struct Desc {
     uint32_t tmpl[5 * CRIM_PMAX * 4 * CRIM_NDMAX];
     // Template rows for the matrix-core search, each zero padded to 16 bytes: [type][row], type
     // 0..2 = k*T per Lab channel (signed), 3 = k.  Only written for patch edges <= MS_PMAX.
-    uint8_t zrows[4][MS_PMAX + 1][16];
+    __attribute__((aligned(16))) uint8_t zrows[4][MS_PMAX + 1][16];
 };
 
 struct Params {
