@@ -260,6 +260,12 @@ static size_t priority_lds_bytes(const Params& p) {
     return rs * rs * 16 + CRIM_TILE * CRIM_TILE * 4 + (CRIM_TILE + 2) * (CRIM_TILE + 2) + 16;
 }
 
+static void launch_update(const Params& p, hipStream_t s) {
+    if (p.P <= 9) hipLaunchKernelGGL(k_update<9>, dim3(p.B), dim3(256), 0, s, p);
+    else if (p.P <= 15) hipLaunchKernelGGL(k_update<15>, dim3(p.B), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(k_update<CRIM_PMAX>, dim3(p.B), dim3(256), 0, s, p);
+}
+
 static void launch_priority(const Params& p, hipStream_t s) {
     const dim3 grid((unsigned)p.pgrid * p.B), block(64);
     const size_t lds = priority_lds_bytes(p);
@@ -284,7 +290,7 @@ static void launch_iteration(const Params& p, hipStream_t s, hipEvent_t ev0 = nu
     if (ev0) (void)hipEventRecord(ev0, s);
     launch_search(p, s);
     if (ev1) (void)hipEventRecord(ev1, s);
-    hipLaunchKernelGGL(k_update, dim3(p.B), dim3(256), 0, s, p);
+    launch_update(p, s);
 }
 
 static int build_graph(Lane& ln, int iters, GraphSet* out) {
@@ -629,7 +635,7 @@ static int run_split(crim_engine* h, long max_iters) {
                 if (r != ncclSuccess)
                     return fail(CRIM_ERR_HIP, "ncclAllGather: %s", g_rccl.error_string ? g_rccl.error_string(r) : "error");
             }
-            hipLaunchKernelGGL(k_update, dim3(p.B), dim3(256), 0, ln.stream, p);
+            launch_update(p, ln.stream);
         }
         done += need;
         HIP_TRY(hipGetLastError());

@@ -1504,6 +1504,9 @@ __global__ __launch_bounds__(256) void k_local_best(Params p, int part, int row0
 // iteration kernel 4: pick the source, copy the patch, maintain every cached field
 // ------------------------------------------------------------------------------------------
 
+// PM bounds the patch edge the instance serves: its LDS arrays are sized for it, so the common small
+// patches leave room for many blocks per CU.
+template <int PM>
 __global__ __launch_bounds__(256) void k_update(Params p) {
     const int b = p.b0 + blockIdx.x;
     ImgState* st = p.st + b;
@@ -1511,7 +1514,6 @@ __global__ __launch_bounds__(256) void k_update(Params p) {
     const int tid = threadIdx.x;
     const int H = p.H, W = p.W, P = p.P;
     const size_t HW = (size_t)H * W;
-    constexpr int PM = CRIM_PMAX;
     constexpr int MR = 3 * PM - 2 + 2;  // mask region edge: patch grown by max(P-1, 2) per side
     constexpr int GR = PM + 4;        // grey region edge for the gradient update
     __shared__ double s_c[4];
