@@ -1537,11 +1537,7 @@ __global__ __launch_bounds__(256) void k_update(Params p) {
     constexpr int NSPEC = 4;
     SEntry spec[NSPEC];
 #pragma unroll
-    for (int k = 0; k < NSPEC; ++k) {
-        const int i = tid + 256 * k;
-        spec[k].cost = INFINITY; spec[k].idx = 0xffffffffu;
-        if (i < cap) spec[k] = sl[i];
-    }
+    for (int k = 0; k < NSPEC; ++k) spec[k] = sl[imin(tid + 256 * k, cap - 1)];   // used only when in range
     const int live = st->live;
     // loop state is read once, up front: thread 0 rewrites it at the end of this kernel
     const int cur = st->cur;
@@ -1568,27 +1564,62 @@ __global__ __launch_bounds__(256) void k_update(Params p) {
     const int mg = P - 1 > 2 ? P - 1 : 2;   // margin of the mask snapshot around the patch
     const int mr0 = r0 - mg, mc0 = c0 - mg;
     const int mrh = ph + 2 * mg, mrw = pw + 2 * mg;
-    for (int e = tid; e < mrh * mrw; e += 256) {
-        const int i = e / mrw, j = e - i * mrw;
-        const int yy = mr0 + i, xx = mc0 + j;
-        uint8_t v = 1;   // beyond the image: a window reaching there is not a candidate
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = mask[(size_t)yy * W + xx];
-        s_m[i * MR + j] = v;
-        s_m0[i * MR + j] = v;
-    }
+    // Every load of this round is unconditional, from a position clamped into the image, and the
+    // out-of-image value is selected afterwards: the requests of a batch travel together.
+    constexpr int NMB = (MR * MR + 255) / 256 < 8 ? (MR * MR + 255) / 256 : 8;   // mask loads per batch
+    constexpr int NGB = (GR * GR + 255) / 256;
+    constexpr int NRF = ((PM + 2) * (PM + 2) + 255) / 256;
     const int gr0 = r0 - 2, gc0 = c0 - 2, grh = ph + 4, grw = pw + 4;
-    for (int e = tid; e < grh * grw; e += 256) {
+    double rfv[NRF];   // confidence (fresh buffer) of this thread's pixels of the box grown by one
+    uint8_t gm[NGB], gg[NGB];
+    {
+        const int ch = ph + 2, cw = pw + 2;
+#pragma unroll
+        for (int k = 0; k < NRF; ++k) {
+            const int e = tid + 256 * k;
+            const int i = e / cw, j = e - i * cw;
+            const int yy = imin(imax(r0 - 1 + i, 0), H - 1), xx = imin(imax(c0 - 1 + j, 0), W - 1);
+            rfv[k] = cnxt[(size_t)yy * W + xx];
+        }
+#pragma unroll
+        for (int k = 0; k < NGB; ++k) {
+            const int e = tid + 256 * k;
+            const int i = e / grw, j = e - i * grw;
+            const size_t q = (size_t)imin(imax(gr0 + i, 0), H - 1) * W + imin(imax(gc0 + j, 0), W - 1);
+            gm[k] = mask[q];
+            gg[k] = grey[q];
+        }
+    }
+    for (int e0 = tid; e0 < mrh * mrw; e0 += 256 * NMB) {
+        uint8_t mvv[NMB];
+#pragma unroll
+        for (int k = 0; k < NMB; ++k) {
+            const int e = e0 + 256 * k;
+            const int i = e / mrw, j = e - i * mrw;
+            mvv[k] = mask[(size_t)imin(imax(mr0 + i, 0), H - 1) * W + imin(imax(mc0 + j, 0), W - 1)];
+        }
+#pragma unroll
+        for (int k = 0; k < NMB; ++k) {
+            const int e = e0 + 256 * k;
+            if (e >= mrh * mrw) continue;
+            const int i = e / mrw, j = e - i * mrw;
+            const int yy = mr0 + i, xx = mc0 + j;
+            // beyond the image: a window reaching there is not a candidate
+            const uint8_t v = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? mvv[k] : (uint8_t)1;
+            s_m[i * MR + j] = v;
+            s_m0[i * MR + j] = v;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NGB; ++k) {
+        const int e = tid + 256 * k;
+        if (e >= grh * grw) continue;
         const int i = e / grw, j = e - i * grw;
         const int yy = gr0 + i, xx = gc0 + j;
         uint8_t v = 0;
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-            const size_t q = (size_t)yy * W + xx;
-            v = mask[q] ? (uint8_t)0 : grey[q];
-        }
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = gm[k] ? (uint8_t)0 : gg[k];
         s_g[i * GR + j] = v;
     }
-    constexpr int NRF = ((PM + 2) * (PM + 2) + 255) / 256;
-    double rfv[NRF];   // confidence (fresh buffer) of this thread's pixels of the box grown by one
     {
         const int ch = ph + 2, cw = pw + 2;
 #pragma unroll
@@ -1596,8 +1627,7 @@ __global__ __launch_bounds__(256) void k_update(Params p) {
             const int e = tid + 256 * k;
             const int i = e / cw, j = e - i * cw;
             const int yy = r0 - 1 + i, xx = c0 - 1 + j;
-            rfv[k] = 0.0;
-            if (e < ch * cw && yy >= 0 && yy < H && xx >= 0 && xx < W) rfv[k] = cnxt[(size_t)yy * W + xx];
+            if (!(e < ch * cw && yy >= 0 && yy < H && xx >= 0 && xx < W)) rfv[k] = 0.0;
         }
     }
 
