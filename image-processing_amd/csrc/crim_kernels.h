@@ -1573,7 +1573,7 @@ __global__ __launch_bounds__(256) void k_update(Params p) {
     double rfv[NRF];   // confidence (fresh buffer) of this thread's pixels of the box grown by one
     uint8_t gm[NGB], gg[NGB];
     {
-        const int ch = ph + 2, cw = pw + 2;
+        const int cw = pw + 2;
 #pragma unroll
         for (int k = 0; k < NRF; ++k) {
             const int e = tid + 256 * k;
