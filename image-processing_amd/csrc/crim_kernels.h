@@ -479,10 +479,15 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
     const int b = p.b0 + img_;
     ImgState* st = p.st + b;
     STAMP_MID(0);
-    if (!st->live) return;
+    // the first list entry is requested together with the loop state (the list's capacity exceeds
+    // the waves per image, so the read is in bounds; it is used only when bx < tcount)
+    const int tile_first = p.tlist[(size_t)b * p.tcap + bx];
+    const int live = st->live;
+    const int nt = (int)st->tcount;
+    const int cur = st->cur;
+    if (!live) return;
     const int H = p.H, W = p.W, half = p.half;
     const size_t HW = (size_t)H * W;
-    const int nt = (int)st->tcount;
     STAMP_MID(1);
     if (bx >= nt) return;
     const int RS = PT > 0 ? CRIM_TILE + PT - 1 : CRIM_TILE + 2 * half;   // edge of the staged region
@@ -492,7 +497,6 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
     uint8_t* s_mask = (uint8_t*)(s_list + CRIM_TILE * CRIM_TILE);
     const int* tl = p.tlist + (size_t)b * p.tcap;
     const int* tf = p.tfront + (size_t)b * p.tnx * p.tny;
-    const int cur = st->cur;
     const double* ccur = p.conf + ((size_t)b * 2 + cur) * HW;
     double* cnxt = p.conf + ((size_t)b * 2 + (cur ^ 1)) * HW;
     const uint8_t* mask = p.mask + b * HW;
@@ -522,7 +526,7 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
     // Rows of staging loads in flight per lane: the whole region when its edge is known at
     // compile time, batches of 16 otherwise.
     constexpr int NRB = PT > 0 ? (CRIM_TILE + PT - 1 + 1) / 2 : 16;
-    int tile_next = tl[bx];
+    int tile_next = tile_first;
     for (int ti = bx; ti < nt; ti += p.pgrid) {
         const int tile = tile_next;
         // Dependent round trips are what this kernel waits on, so independent loads travel
