@@ -792,7 +792,9 @@ __global__ __launch_bounds__(256) void k_select(Params p) {
         e1[q] = (int8_t)planes[(size_t)H * p.Wp + o];
         e2[q] = (int8_t)planes[(size_t)2 * H * p.Wp + o];
     }
-    int soff_local = 0, nk_local = 0;
+    // per-thread contributions, reduced across the wave before they touch LDS (same-address LDS
+    // atomics from every lane serialise)
+    int soff_local = 0, nk_local = 0, rowm_local = 0, chm_local = 0;
 #pragma unroll
     for (int q = 0; q < NEL; ++q) {
         const int e = tid + 256 * q;
@@ -805,9 +807,8 @@ __global__ __launch_bounds__(256) void k_select(Params p) {
             // sum k*T~^2 - sum k*T^2 with T = T~ + 128
             soff_local += -256 * (t0 + t1 + t2) - 3 * 16384;
             ++nk_local;
-            atomicOr(&s_rowmask, 1 << i);
-            const int cm = (t0 ? 1 : 0) | (t1 ? 2 : 0) | (t2 ? 4 : 0);
-            if (cm) atomicOr(&s_chmask, cm);
+            rowm_local |= 1 << i;
+            chm_local |= (t0 ? 1 : 0) | (t1 ? 2 : 0) | (t2 ? 4 : 0);
         }
         s_k[e] = (uint8_t)k;
         s_t[0][e] = (int8_t)t0; s_t[1][e] = (int8_t)t1; s_t[2][e] = (int8_t)t2;
@@ -816,8 +817,21 @@ __global__ __launch_bounds__(256) void k_select(Params p) {
             d->tflat[0][e] = (int8_t)t0; d->tflat[1][e] = (int8_t)t1; d->tflat[2][e] = (int8_t)t2;
         }
     }
-    if (soff_local) atomicAdd(&s_soff, soff_local);
-    if (nk_local) atomicAdd(&s_nk, nk_local);
+    if (__any(nk_local != 0)) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            soff_local += __shfl_xor(soff_local, off);
+            nk_local += __shfl_xor(nk_local, off);
+            rowm_local |= __shfl_xor(rowm_local, off);
+            chm_local |= __shfl_xor(chm_local, off);
+        }
+        if ((tid & 63) == 0) {
+            atomicAdd(&s_soff, soff_local);
+            atomicAdd(&s_nk, nk_local);
+            atomicOr(&s_rowmask, rowm_local);
+            if (chm_local) atomicOr(&s_chmask, chm_local);
+        }
+    }
     __syncthreads();
     STAMP(10);
 
