@@ -1701,12 +1701,15 @@ __global__ __launch_bounds__(256) void k_update(Params p) {
     STAMP(18);
 
     // ---- fill the masked pixels of the target patch (:274-308)
-    int filled = 0;
-    for (int e = tid; e < ph * pw; e += 256) {
+    // (the fill bits and the count go through wave ballots: same-address LDS atomics from every
+    // lane would serialise)
+    for (int e0 = 0; e0 < ph * pw; e0 += 256) {
+        const int e = e0 + tid;
         const int i = e / pw, j = e - i * pw;
-        const int yy = r0 + i, xx = c0 + j;
-        const size_t q = (size_t)yy * W + xx;
-        if (s_m0[(i + mg) * MR + (j + mg)]) {
+        const bool fill = e < ph * pw && s_m0[(i + mg) * MR + (j + mg)];
+        if (fill) {
+            const int yy = r0 + i, xx = c0 + j;
+            const size_t q = (size_t)yy * W + xx;
             bgr[3 * q] = s_px[e][0]; bgr[3 * q + 1] = s_px[e][1]; bgr[3 * q + 2] = s_px[e][2];
             const size_t qo = (size_t)yy * p.Wp + xx;
             for (int k = 0; k < CRIM_NPL; ++k) planes[k * PS + qo] = s_px[e][3 + k];
@@ -1715,11 +1718,16 @@ __global__ __launch_bounds__(256) void k_update(Params p) {
             mask[q] = 0;
             s_m[(i + mg) * MR + (j + mg)] = 0;
             s_g[(i + 2) * GR + (j + 2)] = s_px[e][3 + CRIM_NPL];
-            atomicOr(&s_fill[e >> 5], 1u << (e & 31));
-            ++filled;
+        }
+        const unsigned long long bal = __ballot(fill);
+        if ((tid & 63) == 0 && bal != 0) {
+            const int w = (e0 + tid) >> 5;   // this wave's 64 elements start on an even word
+            constexpr int NW = (PM * PM + 31) / 32;
+            if (w < NW) s_fill[w] = (unsigned)bal;
+            if (w + 1 < NW) s_fill[w + 1] = (unsigned)(bal >> 32);
+            atomicAdd(&s_filled, __popcll(bal));
         }
     }
-    if (filled) atomicAdd(&s_filled, filled);
     __syncthreads();
     STAMP(19);
 
