@@ -489,7 +489,14 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
     const int H = p.H, W = p.W, half = p.half;
     const size_t HW = (size_t)H * W;
     STAMP_MID(1);
-    if (bx >= nt) return;
+    if (bx >= nt) {
+        if (threadIdx.x == 0) {
+            PEntry e;
+            e.prio = -1.0; e.pos = 0x7fffffff; e.pad = 0;
+            p.plist[(size_t)b * p.pgrid + bx] = e;
+        }
+        return;
+    }
     const int RS = PT > 0 ? CRIM_TILE + PT - 1 : CRIM_TILE + 2 * half;   // edge of the staged region
     constexpr int MS = CRIM_TILE + 2;                                    // edge of the staged mask
     uint4* s_el = (uint4*)smem;
@@ -661,11 +668,11 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
         const int oi = __shfl_down(bestI, off_);
         if (better_prio(op, oi, bestP, bestI)) { bestP = op; bestI = oi; }
     }
-    if (lane == 0 && bestP >= 0.0) {
-        const unsigned k = atomicAdd(&st->pcount, 1u);
+    // every wave owns one slot of its image's partial list (an empty entry has priority -1)
+    if (lane == 0) {
         PEntry e;
         e.prio = bestP; e.pos = bestI; e.pad = 0;
-        p.plist[(size_t)b * p.pgrid + k] = e;
+        p.plist[(size_t)b * p.pgrid + bx] = e;
     }
     STAMP_MID(3);
 }
@@ -709,19 +716,15 @@ __global__ __launch_bounds__(256) void k_select(Params p) {
     ImgState* st = p.st + b;
     Desc* d = p.desc + b;
     const int tid = threadIdx.x;
-    // Dependent memory round trips dominate this kernel, so the partial list is read up to its
-    // capacity together with the loop state; entries beyond the count are ignored.
+    // Dependent memory round trips dominate this kernel, so the partial list is read together with
+    // the loop state.
     const PEntry* pl = p.plist + (size_t)b * p.pgrid;
     constexpr int NSPEC = 2;
     PEntry spec[NSPEC];
 #pragma unroll
-    for (int k = 0; k < NSPEC; ++k) {
-        const int i = tid + 256 * k;
-        spec[k].prio = -1.0; spec[k].pos = 0x7fffffff;
-        if (i < p.pgrid) spec[k] = pl[i];
-    }
+    for (int k = 0; k < NSPEC; ++k) spec[k] = pl[imin(tid + 256 * k, p.pgrid - 1)];   // used only when in range
     const int live = st->live;
-    const unsigned n = st->pcount;
+    const unsigned n = (unsigned)p.pgrid;   // one slot per wave of the priority stage
     const int cur = st->cur;
     if (!live) {
         if (tid == 0) d->live = 0;
