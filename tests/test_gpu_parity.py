@@ -87,6 +87,28 @@ def test_vector_dot_product_search_flag(p, colour):
     assert_same_as_oracle(img, m, p, flags=capi.FLAG_DOT4_SEARCH)
 
 
+def test_engine_switches_between_grey_and_colour_uploads():
+    # the 3-plane search instance serves grey engines only: a colour upload must switch the engine
+    # (and its replayed graphs) to the 5-plane instance, and a mixed batch must use it throughout
+    H, W = 72, 96
+    grey, mg = rand_case(190, H, W, noise=False, colour=False)
+    col, mc = rand_case(191, H, W, noise=False, colour=True)
+    og = c_oracle.run(grey, mg, 9)
+    oc = c_oracle.run(col, mc, 9)
+    with capi.Engine(H, W, 9) as eng:
+        for img, m, o in ((grey, mg, og), (col, mc, oc), (grey, mg, og)):
+            eng.upload(img, m)
+            eng.run()
+            out, conf, _ = eng.download(want_conf=True)
+            assert np.array_equal(out[0], o[0]) and np.array_equal(conf[0], o[1])
+            assert np.array_equal(eng.trace(0), o[3].astype(capi.ITER_REC_DTYPE))
+    with capi.Engine(H, W, 9, batch=2) as eng:
+        eng.upload(np.stack([grey, col]), np.stack([mg, mc]))
+        eng.run()
+        out, _, _ = eng.download()
+        assert np.array_equal(out[0], og[0]) and np.array_equal(out[1], oc[0])
+
+
 def test_wide_image_spans_several_search_tiles():
     # 600 columns: three 256-origin tiles per row of matrix-core blocks, the last one partial
     img, m = rand_case(180, 40, 600, noise=True, colour=True)

@@ -28,3 +28,6 @@ for it in range(20):
     acc.setdefault("gaps", []).append(np.array([st[8] - st[3], st[16] - st[11]]) * 10)
 for k, v in acc.items():
     print(k, "mean ns per phase:", np.mean(v, axis=0).astype(int).tolist(), "total", int(np.mean(np.sum(v, axis=1))))
+st = np.zeros(64, np.int64); lib.crim_debug_stamps(eng._h, st.ctypes.data)
+if st[51]:
+    print("search: priced windows %d in %d blocks -> %.2f per block" % (st[50], st[51], st[50] / st[51]))
