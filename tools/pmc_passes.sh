@@ -27,7 +27,7 @@ for name in ("valu", "lds", "fetch", "write", "grbm"):
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         disp[k].add(r["Dispatch_Id"])
     for k in agg:
-        if "k_search" in k or "k_priority" in k or k in ("k_update", "k_select"):
+        if any(s in k for s in ("k_search", "k_priority", "k_update", "k_select")):
             n = len(disp[k])
             summary.setdefault(k, {})["launches_" + name] = n
             for c, v in agg[k].items():
