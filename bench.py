@@ -204,11 +204,12 @@ def main():
             ms, launches, evals = pe.profile()
         # Roofs for the search of a batch of grey images.  HBM: every iteration reads, per image,
         # the three byte planes it scores (L-128 and the two digits of Q) and the window-validity
-        # map once: 4 bytes per pixel, i.e. 4*H*W / ((H-8)*(W-8)) bytes per window scored; the
-        # working set (gigabytes) is far beyond L2 and the 256 MB Infinity Cache.  MFMA: 243
-        # algorithmic multiply-accumulates per window (960 issued, see the note).  The HBM roof is
-        # the nearer one (67 us against 48 us per launch of 2048 images), so it is the one reported.
-        bytes_per_window = 4.0 * H * W / ((H - PATCH + 1) * (W - PATCH + 1))
+        # bitmap once: 3 + 1/8 bytes per pixel, i.e. 3.125*H*W / ((H-8)*(W-8)) bytes per window
+        # scored; the working set (gigabytes) is far beyond L2 and the 256 MB Infinity Cache.
+        # MFMA: 243 algorithmic multiply-accumulates per window (960 issued, see the note).  The
+        # HBM roof is the nearer one (per launch of 2048 images: 52 us against 48 us of issued
+        # MFMA work, 24 us of algorithmic MFMA work), so it is the one reported.
+        bytes_per_window = 3.125 * H * W / ((H - PATCH + 1) * (W - PATCH + 1))
         algo_bytes = evals * bytes_per_window
         achieved = algo_bytes / (ms * 1e-3) / 1e9
         ops = evals * PATCH * PATCH * 3 * 2
@@ -222,11 +223,11 @@ def main():
             "algorithmic_bytes_per_launch": algo_bytes / max(launches, 1),
             "mfma_achieved_tops": ops / (ms * 1e-3) / 1e12, "mfma_peak_tops": MFMA_I8_PEAK_TOPS,
             "mfma_frac": ops / (ms * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS,
-            "note": "algorithmic bytes = 4 B per pixel per image per iteration (3 byte planes + validity "
-                    "map), one launch covers one lane = half the batch; traffic = HBM-side bytes per "
+            "note": "algorithmic bytes = 3.125 B per pixel per image per iteration (3 byte planes + validity "
+                    "bitmap), one launch covers one lane = half the batch; traffic = HBM-side bytes per "
                     "launch from the committed PMC passes (profiles/; FETCH_SIZE doubled for 16-byte "
-                    "loads, plus WRITE_SIZE), above the algorithmic figure because tiles overlap by 9 of "
-                    "41 rows; mfma_*: integer ops (2 per MAC) against the dense i8 MFMA peak, 243 "
+                    "loads, plus WRITE_SIZE): tiles overlap by 9 of 41 rows, and the blocks of one image "
+                    "share an XCD so that its L2 serves most of that overlap; mfma_*: integer ops (2 per MAC) against the dense i8 MFMA peak, 243 "
                     "algorithmic MAC per window of 960 issued (each template row occupies 32 K-slots: 16 "
                     "x shifts + 9 taps, padded; two rows per v_mfma_i32_16x16x64_i8)",
         }

@@ -65,6 +65,32 @@ __device__ __forceinline__ void xcd_decode(unsigned id, int per_image, int nimg,
 }
 
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int imax_(int a, int b) { return a > b ? a : b; }
+
+// Cross-lane helpers on the DPP path (no LDS round trip, unlike ds_bpermute-based shuffles).
+// Lane l receives lane l ^ 1 / l ^ 2 of its quad:
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = dpp_i32<CTRL>(__double2loint(v)), hi = dpp_i32<CTRL>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+#define DPP_QUAD_XOR1 0xB1   // quad_perm [1,0,3,2]
+#define DPP_QUAD_XOR2 0x4E   // quad_perm [2,3,0,1]
+// Maximum over the 64 lanes of a wave, returned to every lane: quads, half rows, rows by DPP
+// permutes, then the row results are carried along by row broadcasts into lane 63.
+__device__ __forceinline__ int wave_max_i32(int v) {
+    v = imax_(v, dpp_i32<DPP_QUAD_XOR1>(v));
+    v = imax_(v, dpp_i32<DPP_QUAD_XOR2>(v));
+    v = imax_(v, dpp_i32<0x141>(v));   // row_half_mirror
+    v = imax_(v, dpp_i32<0x140>(v));   // row_mirror: every lane holds its row's maximum
+    v = imax_(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false));   // row_bcast15 into rows 1, 3
+    v = imax_(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false));   // row_bcast31 into rows 2, 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 
 // A rectangular window of a 2-D field: element (y, x) in image coordinates lives `stride` bytes
@@ -637,12 +663,12 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
                 constexpr int EL = PT * PT - 1;   // the one tail element: PT*PT = 1 (mod 8)
                 const uint4 tl_ = *(const uint4*)(eb + ((PT - 1) * RS + (PT - 1)) * 16);
                 double t = r0 + r1;
-                t = t + __shfl_xor(t, 1, PG);
-                t = t + __shfl_xor(t, 2, PG);
+                t = t + dpp_f64<DPP_QUAD_XOR1>(t);
+                t = t + dpp_f64<DPP_QUAD_XOR2>(t);
                 t += __hiloint2double((int)tl_.y, (int)tl_.x);
-                unsigned ob = (unsigned)__shfl_xor((int)best, 1, PG);
+                unsigned ob = (unsigned)dpp_i32<DPP_QUAD_XOR1>((int)best);
                 best = ob > best ? ob : best;
-                ob = (unsigned)__shfl_xor((int)best, 2, PG);
+                ob = (unsigned)dpp_i32<DPP_QUAD_XOR2>((int)best);
                 best = ob > best ? ob : best;
                 const unsigned kt = tl_.z + (1023u - (unsigned)EL);
                 best = kt > best ? kt : best;
@@ -1388,9 +1414,7 @@ void k_search_mfma(Params p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) tmax = imax(tmax, acc[yy][j]);
     }
-    int wmax = tmax;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) wmax = imax(wmax, __shfl_xor(wmax, off));
+    const int wmax = wave_max_i32(tmax);
     const int gbound = s_bound;
     if (lane == 0 && wmax > -(POISON << 7)) {
         const long long u = (long long)soff - wmax + p.dmax + 1;
@@ -1417,13 +1441,20 @@ void k_search_mfma(Params p) {
     }
     STAMP_MID(39);
     if (tid == 0 && ub < gbound) atomicMin(&p.st[b].bound, ub);
-    // waves without a priced window skip the shuffle reduction
-    if (__any(bi != 0xffffffffu)) {
-        for (int off = 32; off > 0; off >>= 1) {
-            const double oc = __shfl_down(bc, off);
-            const unsigned oi = __shfl_down(bi, off);
-            if (better_cost(oc, oi, bc, bi)) { bc = oc; bi = oi; }
+    // the few lanes that priced a window are read out one by one (wave-uniform loop)
+    {
+        unsigned long long m = __ballot(bi != 0xffffffffu);
+        double wc = INFINITY;
+        unsigned wi = 0xffffffffu;
+        while (m) {
+            const int l = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const double c = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(bc), l),
+                                              __builtin_amdgcn_readlane(__double2loint(bc), l));
+            const unsigned i = (unsigned)__builtin_amdgcn_readlane((int)bi, l);
+            if (better_cost(c, i, wc, wi)) { wc = c; wi = i; }
         }
+        bc = wc; bi = wi;
     }
     if (lane == 0) { s_c[wv] = bc; s_i[wv] = bi; }
     __syncthreads();
