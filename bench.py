@@ -36,9 +36,12 @@ MFMA_I8_PEAK_TOPS = 5033.2         # 256 CU x 4 SIMD x 1024 MAC/clk x 2 op x 2.4
 HBM_PEAK_GBS = 8000.0              # HBM3E
 
 
+COLOUR = False
+
+
 def _make_one(seed):
     import crim_synth
-    return (crim_synth.xray_like(H, W, seed, colour=False),
+    return (crim_synth.xray_like(H, W, seed, colour=COLOUR),
             crim_synth.blob_mask(H, W, seed, fraction=MASK_FRACTION, margin=PATCH))
 
 
@@ -61,17 +64,18 @@ def make_batch(batch, rank):
     return imgs, masks
 
 
-def pmc_traffic_per_launch():
-    """HBM-side bytes per search launch from the committed rocprofv3 PMC passes of this same
+def pmc_traffic_per_launch(images_per_launch):
+    """HBM-side bytes per search launch from the committed rocprofv3 PMC passes of the default
     command (FETCH_SIZE and WRITE_SIZE are collected in separate runs, tools/pmc_passes.sh; they
-    cannot be read from inside the benchmark).  FETCH_SIZE is doubled: the search stages its
-    tiles with 16-byte-per-lane coalesced loads, which gfx950 tallies at half their bytes.
-    None when no PMC summary is present."""
+    cannot be read from inside the benchmark), scaled to this run's images per launch.
+    FETCH_SIZE is doubled: the search stages its tiles with 16-byte-per-lane coalesced loads,
+    which gfx950 tallies at half their bytes.  None when no PMC summary is present."""
     path = os.path.join(ROOT, "profiles", "pmc_search_latest.json")
     try:
         with open(path) as f:
             d = json.load(f)
-        return (2.0 * d["FETCH_SIZE_KB_per_launch"] + d["WRITE_SIZE_KB_per_launch"]) * 1024.0
+        per_launch = (2.0 * d["FETCH_SIZE_KB_per_launch"] + d["WRITE_SIZE_KB_per_launch"]) * 1024.0
+        return per_launch * images_per_launch / float(d.get("images_per_launch", 2048))
     except (OSError, KeyError, ValueError):
         return None
 
@@ -112,7 +116,12 @@ def main():
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--colour", action="store_true",
+                    help="false-colour images (5-plane search) instead of the grey ones of BASELINE configs[1]; "
+                         "side measurement, run with --no-roofline")
     args = ap.parse_args()
+    global COLOUR
+    COLOUR = args.colour
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -133,10 +142,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
+    # Rehearsal knobs (several ranks on a box with fewer GPUs): BENCH_DEVICE pins every rank to one
+    # device, BENCH_BACKEND=gloo replaces RCCL, which refuses two ranks on one GPU.
+    if "BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["BENCH_DEVICE"])
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     # inputs resident in HBM before the timed region
     d_img = torch.from_numpy(imgs).cuda()
@@ -165,7 +182,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -213,7 +230,7 @@ def main():
         algo_bytes = evals * bytes_per_window
         achieved = algo_bytes / (ms * 1e-3) / 1e9
         ops = evals * PATCH * PATCH * 3 * 2
-        traffic = pmc_traffic_per_launch()
+        traffic = pmc_traffic_per_launch(B / 2.0 if B >= 32 else B)
         result["evals_per_s_per_gpu"] = evals / (ms * 1e-3)
         result["roofline"] = {
             "bound": "hbm", "kernel": "k_search_mfma<9, false>",
