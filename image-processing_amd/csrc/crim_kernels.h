@@ -1204,7 +1204,7 @@ __global__ __launch_bounds__(256) void k_search(Params p) {
 // LARGEST accumulator.  Inadmissible windows start from -2^20, i.e. end 2^28 too low.
 typedef int v4i __attribute__((ext_vector_type(4)));
 #ifndef MS_WPE
-#define MS_WPE(P, CHROMA) (((CHROMA) || (P) > 11) ? 2 : ((P) > 9 ? 3 : 4))
+#define MS_WPE(P, CHROMA) ((P) > 11 ? 2 : (((CHROMA) || (P) > 9) ? 3 : 4))
 #endif
 
 // CHROMA = false serves engines whose images are all grey: only the L channel and the two Q
@@ -1220,9 +1220,12 @@ void k_search_mfma(Params p) {
     constexpr int NCH = LROWS * C16;
     constexpr int NIT = (NCH + 255) / 256;
     constexpr int POISON = 1 << 20;
-    constexpr int NSLOT = CHROMA ? 5 : 3;       // LDS slots: Lab channel(s), l digit, h digit
+    // Three LDS slots hold plane tiles.  Grey engines: L, l digit, h digit, staged once.  Colour
+    // engines need five planes: h, L, a are staged first, b and the l digit follow into the
+    // slots of h and L while the passes over the resident planes run (three more barriers).
+    constexpr int NSLOT = 3;
     constexpr int NCC = CHROMA ? 3 : 1;         // cross-term channels
-    constexpr int SLOT_L = NSLOT - 2, SLOT_H = NSLOT - 1;
+    constexpr int SLOT_L = 1, SLOT_H = CHROMA ? 0 : 2;
     __shared__ __attribute__((aligned(16))) uint8_t lds[NSLOT][LROWS][MS_PITCH];
     // template rows, [type 0..NCC-1 = k*T per channel, NCC = k][row][48]: 16 zero bytes, the row
     // padded to 16, 16 zero bytes -- a lane's operand bytes are an unaligned 16-byte window of it
@@ -1276,10 +1279,11 @@ void k_search_mfma(Params p) {
             zv = *(const uint4*)d->zrows[type == NCC ? 3 : type][row];
     }
     const uint8_t* pl = p.planes + (size_t)b * CRIM_NPL * H * p.Wp;
-    int loff[NIT];
+    int loff[NIT], goff[NIT];
     uint4 v[NSLOT][NIT];
+    // plane staged first into each slot
+    auto first_plane = [](int s) { return CHROMA ? (s == 0 ? 6 : s - 1) : (s == 0 ? 0 : s + 4); };
     {
-        int goff[NIT];
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
             const int c = tid + k * 256;
@@ -1290,9 +1294,7 @@ void k_search_mfma(Params p) {
         }
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s) {
-            if (s < NCC && !((chmask >> s) & 1)) continue;
-            const int plane = s < NCC ? s : (s - NCC + 5);
-            const uint8_t* src = pl + (size_t)plane * H * p.Wp;
+            const uint8_t* src = pl + (size_t)first_plane(s) * H * p.Wp;
 #pragma unroll
             for (int k = 0; k < NIT; ++k) {
                 v[s][k] = make_uint4(0, 0, 0, 0);
@@ -1335,7 +1337,6 @@ void k_search_mfma(Params p) {
     STAMP_MID(33);
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) {
-        if (s < NCC && !((chmask >> s) & 1)) continue;
 #pragma unroll
         for (int k = 0; k < NIT; ++k)
             if (loff[k] >= 0) *(uint4*)(&lds[s][0][0] + loff[k]) = v[s][k];
@@ -1348,7 +1349,8 @@ void k_search_mfma(Params p) {
     __syncthreads();
     STAMP_MID(35);
 
-    if (__any(anyvalid)) {
+    {
+        const bool wave_on = __any(anyvalid);   // a wave without an admissible window only helps staging
         const int g = lane >> 4;
         const int aoff = (wv * R + (g >> 1)) * MS_PITCH + 16 * ((lane & 15) + (g & 1));
         // Operand fragment of step s: lane (n = lane & 15, g) holds, for byte j = 0..15, template
@@ -1368,11 +1370,6 @@ void k_search_mfma(Params p) {
                 Bf[s][3] = (int)__builtin_amdgcn_alignbyte(w4, w3, sh);
             }
         };
-        v4i Bk[NS], Bc[NCC][NS];
-        fragments(NCC, Bk);
-#pragma unroll
-        for (int t = 0; t < NCC; ++t)
-            if ((chmask >> t) & 1) fragments(t, Bc[t]);
         auto plane_pass = [&](int slot, const v4i* Bf) {
             const uint8_t* base = &lds[slot][0][0] + aoff;
 #pragma unroll
@@ -1386,15 +1383,62 @@ void k_search_mfma(Params p) {
                 }
             }
         };
-        plane_pass(SLOT_H, Bk);
+        v4i Bk[NS], Bc[NS];
+        fragments(NCC, Bk);
+        if constexpr (!CHROMA) {
+            if (wave_on) {
+                plane_pass(SLOT_H, Bk);
 #pragma unroll
-        for (int yy = 0; yy < R; ++yy) acc[yy] <<= 7;
+                for (int yy = 0; yy < R; ++yy) acc[yy] <<= 7;
+                if (chmask & 1) {
+                    fragments(0, Bc);
+                    plane_pass(0, Bc);
+                }
 #pragma unroll
-        for (int t = 0; t < NCC; ++t)
-            if ((chmask >> t) & 1) plane_pass(t, Bc[t]);
+                for (int yy = 0; yy < R; ++yy) acc[yy] <<= 1;
+                plane_pass(SLOT_L, Bk);
+            }
+        } else {
+            uint4 vn[NIT];
+            auto request = [&](int plane) {
+                const uint8_t* src = pl + (size_t)plane * H * p.Wp;
 #pragma unroll
-        for (int yy = 0; yy < R; ++yy) acc[yy] <<= 1;
-        plane_pass(SLOT_L, Bk);
+                for (int k = 0; k < NIT; ++k) {
+                    vn[k] = make_uint4(0, 0, 0, 0);
+                    if (goff[k] >= 0) vn[k] = *(const uint4*)(src + goff[k]);
+                }
+            };
+            auto deposit = [&](int slot) {
+#pragma unroll
+                for (int k = 0; k < NIT; ++k)
+                    if (loff[k] >= 0) *(uint4*)(&lds[slot][0][0] + loff[k]) = vn[k];
+            };
+            if (wave_on) plane_pass(0, Bk);                 // h digits
+#pragma unroll
+            for (int yy = 0; yy < R; ++yy) acc[yy] <<= 7;
+            request(2);                                     // b travels during the L pass
+            if (wave_on && (chmask & 1)) {
+                fragments(0, Bc);
+                plane_pass(1, Bc);                          // L
+            }
+            __syncthreads();                                // every wave is past the h and L passes
+            deposit(0);                                     // b replaces h
+            request(5);                                     // the l digits travel during the a pass
+            if (wave_on && (chmask & 2)) {
+                fragments(1, Bc);
+                plane_pass(2, Bc);                          // a
+            }
+            __syncthreads();                                // b is visible
+            deposit(1);                                     // l digits replace L
+            if (wave_on && (chmask & 4)) {
+                fragments(2, Bc);
+                plane_pass(0, Bc);                          // b
+            }
+            __syncthreads();                                // the l digits are visible
+#pragma unroll
+            for (int yy = 0; yy < R; ++yy) acc[yy] <<= 1;
+            if (wave_on) plane_pass(1, Bk);                 // l digits
+        }
     }
 
     STAMP_MID(36);
