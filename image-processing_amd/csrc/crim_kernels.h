@@ -379,16 +379,31 @@ __global__ __launch_bounds__(256) void k_init_fields(Params p, int first) {
     const int x = blockIdx.x * CRIM_TILE + (threadIdx.x & 15);
     const size_t HW = (size_t)p.H * p.W;
     const uint8_t* mk = p.mask + b * HW;
+    // Mask rows of the tile grown by P-1 to the right and below as bit rows (bit j = pixel
+    // tx0 + j masked or beyond the image), by wave ballots; a window is inadmissible when the OR of
+    // its P rows has a bit set among its P columns.
+    __shared__ unsigned long long s_rowbits[CRIM_TILE + CRIM_PMAX - 1];
+    {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int tx0 = blockIdx.x * CRIM_TILE, ty0 = blockIdx.y * CRIM_TILE;
+        const int nrows = CRIM_TILE + p.P - 1;
+        const int xx = tx0 + lane;
+        for (int r = wave; r < nrows; r += 4) {
+            const int yy = ty0 + r;
+            bool m = false;
+            if (lane < nrows) m = (yy >= p.H || xx >= p.W) ? true : mk[(size_t)yy * p.W + xx] != 0;
+            const unsigned long long bal = __ballot(m);
+            if (lane == 0) s_rowbits[r] = bal;
+        }
+    }
+    __syncthreads();
     int isfront = 0, inv_bit = 1;
     if (y < p.H && x < p.W) {
         p.grad[b * HW + (size_t)y * p.W + x] = grad_packed(p.grey + b * HW, mk, p.H, p.W, y, x);
-        int inv = 1;
-        if (y <= p.H - p.P && x <= p.W - p.P) {
-            inv = 0;
-            for (int i = 0; i < p.P && !inv; ++i)
-                for (int j = 0; j < p.P; ++j)
-                    if (mk[(size_t)(y + i) * p.W + x + j]) { inv = 1; break; }
-        }
+        const int py = threadIdx.x >> 4, px = threadIdx.x & 15;
+        unsigned long long rows = 0;
+        for (int i = 0; i < p.P; ++i) rows |= s_rowbits[py + i];
+        const int inv = ((rows >> px) & ((1ull << p.P) - 1ull)) != 0;
         p.invalid[((size_t)b * p.H + y) * p.Wi + x] = (uint8_t)inv;
         inv_bit = inv;
         int nb[9];
