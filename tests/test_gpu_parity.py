@@ -370,6 +370,23 @@ def test_512_prefix_and_properties():
     assert tr["sy"].max() <= 512 - 9 and tr["sx"].max() <= 512 - 9
 
 
+@pytest.mark.parametrize("p,iters", [(9, 4), (15, 2)])
+def test_2048_prefix(p, iters):
+    """BASELINE configs[3] shape (2048x2048x3, 1024x1024 hole): the first iterations against the
+    oracle (a full CPU run would take hours), eight 256-origin tiles per row of search blocks."""
+    S = 2048
+    img = crim_synth.xray_like(S, S, 4000 + S, colour=True)
+    mask = crim_synth.square_hole_mask(S, S, S // 2)
+    oout, oconf, omask, otr, n = c_oracle.run(img, mask, p, max_iters=iters)
+    with capi.Engine(S, S, p) as eng:
+        eng.upload(img, mask)
+        eng.run(max_iters=iters)
+        out, conf, msk = eng.download(want_conf=True, want_mask=True)
+        tr = eng.trace(0)
+    assert np.array_equal(tr, otr.astype(capi.ITER_REC_DTYPE))
+    assert np.array_equal(out[0], oout) and np.array_equal(conf[0], oconf) and np.array_equal(msk[0], omask)
+
+
 def test_device_mask_recipe_and_inpaint_image():
     """The GPU mask builder against the NumPy restatement of src/utils.py:79-100, and the
     inpaint_image mirror end to end against the committed fixture of a reference dataset image."""
