@@ -211,6 +211,8 @@ __device__ __forceinline__ double pw_sum8<0>(const PatchReader& a, int lo, int n
 // front pixel, computed by PG cooperating lanes (l = lane index within the group; all PG lanes
 // must call this together and all receive the result).  conf is the confidence map before this
 // iteration's update, nb the pixel's 3x3 mask neighbourhood, F its front weight.
+// D is the halving depth of the pairwise sum: 0 when the patch is known to hold at most 128 pixels.
+template <int D = 3>
 __device__ __forceinline__ FrontEval eval_front_pixel(const Params& p, const View<int>& grad,
                                                       const View<double>& conf, int y, int x, int F,
                                                       const int nb[9], int l) {
@@ -223,7 +225,7 @@ __device__ __forceinline__ FrontEval eval_front_pixel(const Params& p, const Vie
     rd.c = conf; rd.r0 = r0; rd.c0 = c0; rd.pw = pw;
     rd.inv = (65536u + (unsigned)pw - 1u) / (unsigned)pw;
     FrontEval out;
-    out.cnew = pw_sum8<3>(rd, 0, n, l) / (double)p.psq;
+    out.cnew = pw_sum8<D>(rd, 0, n, l) / (double)p.psq;
 
     // mask normal (:138-164): Sobel/4 correlation, then normalised
     const double a = nb[0], b = nb[1], c = nb[2], d = nb[3], f = nb[5], g = nb[6], h = nb[7],
@@ -692,7 +694,7 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
                 const int bpk = (int)((const uint4*)eb)[brow * RS + bcol].w;
                 ev = finish_front_pixel(t / (double)p.psq, nb, F, bpk);
             } else {
-                ev = eval_front_pixel(p, vgrad, vconf, fy, fx, F, nb, l);
+                ev = eval_front_pixel<(PT > 0 ? 0 : 3)>(p, vgrad, vconf, fy, fx, F, nb, l);
             }
             if (l == 0) {
                 const int pos = fy * W + fx;
