@@ -556,17 +556,26 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
     double bestP = -1.0;
     int bestI = 0x7fffffff;
 
+    // per-lane-of-group table of record offsets (LDS, not registers: the registers buy a fourth
+    // wave per SIMD): s_off[l][2i + k] = byte offset of flattened element 8i + 2l + k
     constexpr int NE = PT > 0 ? (PT * PT) / 8 : 1;
-    int off[2 * NE];
+    int2* s_off = (int2*)(((uintptr_t)(s_mask + MS * MS) + 7) & ~(uintptr_t)7);
     if (PT > 0) {
-#pragma unroll
-        for (int i = 0; i < NE; ++i)
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int e = 8 * i + 2 * l + k;
+        for (int t = lane; t < PG * NE; t += 64) {
+            const int ll = t / NE, i = t - ll * NE;
+            int2 o;
+            {
+                const int e = 8 * i + 2 * ll;
                 const int row = e / (PT > 0 ? PT : 1), col = e - row * PT;
-                off[2 * i + k] = (row * RS + col) * 16;
+                o.x = (row * RS + col) * 16;
             }
+            {
+                const int e = 8 * i + 2 * ll + 1;
+                const int row = e / (PT > 0 ? PT : 1), col = e - row * PT;
+                o.y = (row * RS + col) * 16;
+            }
+            s_off[ll * NE + i] = o;
+        }
     }
     // staging geometry: lanes cover one (RS <= 32) or half a (RS <= 64) staged row per pass
     const int sh = RS <= 32 ? 5 : 6;
@@ -668,8 +677,9 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
                 const unsigned kb = 1023u - 2u * (unsigned)l;
 #pragma unroll 5
                 for (int i = 0; i < NE; ++i) {
-                    const uint4 a = *(const uint4*)(eb + off[2 * i]);
-                    const uint4 c = *(const uint4*)(eb + off[2 * i + 1]);
+                    const int2 o = s_off[l * NE + i];
+                    const uint4 a = *(const uint4*)(eb + o.x);
+                    const uint4 c = *(const uint4*)(eb + o.y);
                     const double ca = __hiloint2double((int)a.y, (int)a.x);
                     const double cc = __hiloint2double((int)c.y, (int)c.x);
                     if (i == 0) { r0 = ca; r1 = cc; } else { r0 += ca; r1 += cc; }
