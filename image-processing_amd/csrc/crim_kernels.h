@@ -1664,6 +1664,7 @@ __global__ __launch_bounds__(256) void k_update(Params p) {
     const int live = st->live;
     // loop state is read once, up front: thread 0 rewrites it at the end of this kernel
     const int cur = st->cur;
+    const int remaining0 = st->remaining, iter0 = st->iter;
     const int ncx = d->ncx;
     // entries to reduce: the exchange slots of a split search, else the slots of the search blocks
     // inside the candidate grid
@@ -1971,8 +1972,8 @@ __global__ __launch_bounds__(256) void k_update(Params p) {
     // ---- loop state and trace
     if (tid == 0) {
         const int nf = s_filled;
-        const int rem = st->remaining - nf;
-        const int it = st->iter;
+        const int rem = remaining0 - nf;
+        const int it = iter0;
         if (p.trace && it < p.trace_cap) {
             crim_iter_rec rec;
             rec.tr = d->tr; rec.tc = d->tc; rec.sy = sy; rec.sx = sx;
