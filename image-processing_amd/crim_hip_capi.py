@@ -24,6 +24,7 @@ FLAG_EAGER = 1
 FLAG_PROFILE = 2
 FLAG_GENERIC_SEARCH = 4
 FLAG_DOT4_SEARCH = 8
+FLAG_PROFILE_SOLO = 16
 
 MAX_PATCH = 31
 

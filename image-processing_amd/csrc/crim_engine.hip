@@ -364,7 +364,8 @@ extern "C" int crim_create_batch(int batch, int H, int W, int patch_size, int de
     if (!h) return fail(CRIM_ERR_NOMEM, "crim_create: out of host memory");
     h->device = device;
     h->flags = flags;
-    if (flags & CRIM_FLAG_PROFILE) h->flags |= CRIM_FLAG_EAGER;
+    if (flags & CRIM_FLAG_PROFILE_SOLO) h->flags |= CRIM_FLAG_PROFILE;
+    if (h->flags & CRIM_FLAG_PROFILE) h->flags |= CRIM_FLAG_EAGER;
     h->patch_size = patch_size;
     Params& p = h->prm;
     memset(&p, 0, sizeof(p));
@@ -698,6 +699,7 @@ extern "C" int crim_run(crim_t* h, long max_iters, long* iters_done, long* remai
     Params& p = h->prm;
     const bool profile = (h->flags & CRIM_FLAG_PROFILE) != 0;
     const bool eager = (h->flags & CRIM_FLAG_EAGER) != 0;
+    const bool solo = (h->flags & CRIM_FLAG_PROFILE_SOLO) != 0;
     for (auto& ln : h->lanes) ln.done = 0;
     int rc = CRIM_OK;
     if (h->split_parts > 0) {
@@ -728,7 +730,24 @@ extern "C" int crim_run(crim_t* h, long max_iters, long* iters_done, long* remai
             if (max_iters > 0) need = std::min(need, max_iters - ln.done);
             if (need <= 0) continue;
             any = true;
-            if (profile) {
+            if (profile && !solo) {
+                // as the loop runs in production: the lanes overlap, every search launch bracketed
+                for (long i = 0; i < need; ++i) {
+                    if ((ln.done + i) > 0 && (ln.done + i) % COMPACT_PERIOD == 0) launch_compact(lp, ln.stream);
+                    if (2 * h->ev_used == (int)h->ev.size()) {
+                        hipEvent_t a = nullptr, b = nullptr;
+                        HIP_TRY(hipEventCreate(&a));
+                        HIP_TRY(hipEventCreate(&b));
+                        h->ev.push_back(a);
+                        h->ev.push_back(b);
+                        h->ev_evals.push_back(0.0);
+                    }
+                    h->ev_evals[h->ev_used] = 0.0;   // counted from the iteration counters at the end
+                    launch_iteration(lp, ln.stream, h->ev[2 * h->ev_used], h->ev[2 * h->ev_used + 1]);
+                    ++h->ev_used;
+                }
+                ln.done += need;
+            } else if (profile) {
                 // one iteration per round so that the number of live images per launch is known
                 const double evals = (double)live * (double)std::max(p.H - p.P + 1, 0) * (double)std::max(p.W - p.P + 1, 0);
                 h->ev_evals[h->ev_used] = evals;
@@ -761,16 +780,25 @@ extern "C" int crim_run(crim_t* h, long max_iters, long* iters_done, long* remai
         HIP_TRY(hipGetLastError());
         if (!any) break;
         for (auto& ln : h->lanes) HIP_TRY(hipStreamSynchronize(ln.stream));
+        if (profile && !solo) {
+            const int r2 = flush_profile(h);
+            if (r2) return r2;
+        }
     }
     if (profile) {
         const int r2 = flush_profile(h);
         if (r2) return r2;
     }
     long it = 0, rem = 0;
+    double searched = 0.0;
     for (int i = 0; i < p.B; ++i) {
         it = std::max(it, (long)h->h_state[i].iter);
         rem += h->h_state[i].remaining;
+        searched += (double)h->h_state[i].iter;
     }
+    // an image is searched once in every iteration it takes part in
+    if (profile && !solo && h->split_parts == 0)
+        h->prof_evals = searched * (double)std::max(p.H - p.P + 1, 0) * (double)std::max(p.W - p.P + 1, 0);
     if (iters_done) *iters_done = it;
     if (remaining) *remaining = rem;
     if (rc == CRIM_ERR_NO_PROGRESS)

@@ -51,10 +51,13 @@ enum {
 /* crim_create* flags */
 enum {
     CRIM_FLAG_EAGER = 1u,          /* launch kernels one by one instead of replaying a hipGraph */
-    CRIM_FLAG_PROFILE = 2u,        /* bracket every search launch with HIP events (implies eager) */
+    CRIM_FLAG_PROFILE = 2u,        /* bracket every search launch with HIP events (implies eager);
+                                      the lanes of a batch overlap as they do in production */
     CRIM_FLAG_GENERIC_SEARCH = 4u, /* use the unspecialised search kernel for every patch size */
-    CRIM_FLAG_DOT4_SEARCH = 8u     /* use the vector dot-product search kernel instead of the
+    CRIM_FLAG_DOT4_SEARCH = 8u,    /* use the vector dot-product search kernel instead of the
                                       matrix-core one (patch sizes 3..16) */
+    CRIM_FLAG_PROFILE_SOLO = 16u   /* as CRIM_FLAG_PROFILE, but every bracketed search launch has the
+                                      GPU to itself (the stream is drained after each iteration) */
 };
 
 /* Largest patch_size accepted.  The reference takes any integer (:18); the bit-exact regime

@@ -8,5 +8,6 @@ timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpu
 cp $R/gpurun_out/prof_$TAG/*/*kernel_stats.csv $R/gpurun_out/${TAG}_kernel_stats.csv
 grep "^{\"metric\"" $R/gpurun_out/prof_$TAG.log > $R/gpurun_out/${TAG}_bench_under_rocprof.json
 cut -c1-150 $R/gpurun_out/${TAG}_kernel_stats.csv | head -12
+python3 $R/tools/search_duration_by_phase.py $R/gpurun_out/prof_$TAG/*/*kernel_trace.csv 562 | tee $R/gpurun_out/${TAG}_search_duration_by_phase.txt
 bash $R/tools/pmc_passes.sh > $R/gpurun_out/${TAG}_pmc_totals.txt 2>&1 || exit 1
 tail -25 $R/gpurun_out/${TAG}_pmc_totals.txt
