@@ -224,6 +224,25 @@ static void launch_search(const Params& pin, hipStream_t s, int sy0 = 0, int row
         // SB_H == MS_ROWS: the block rows of both specialised kernels coincide
         p.mgx = (std::max(p.W - p.half, 1) + MS_W - 1) / MS_W;
         p.mrows = rows;
+        static const int pipe_t = [] { const char* e = getenv("CRIM_PIPE_T"); return e ? atoi(e) : 8; }();
+        if (!p.chroma && pipe_t > 0) {
+            // pipelined kernel: up to pipe_t rows of tiles per block, fewer when the launch would
+            // otherwise have too few blocks to fill the GPU
+            int T = std::min(pipe_t, rows);
+            while (T > 1 && (long)p.mgx * ((rows + T - 1) / T) * p.B < 3072) T = (T + 1) / 2;
+            p.mtiles = T;
+            p.mchunks = (rows + T - 1) / T;
+            dim3 pgrid((unsigned)p.mgx * p.mchunks * p.B);
+            switch (p.P) {
+                case 3: hipLaunchKernelGGL(k_search_pipe<3>, pgrid, block, 0, s, p); return;
+                case 5: hipLaunchKernelGGL(k_search_pipe<5>, pgrid, block, 0, s, p); return;
+                case 7: hipLaunchKernelGGL(k_search_pipe<7>, pgrid, block, 0, s, p); return;
+                case 9: hipLaunchKernelGGL(k_search_pipe<9>, pgrid, block, 0, s, p); return;
+                case 11: hipLaunchKernelGGL(k_search_pipe<11>, pgrid, block, 0, s, p); return;
+                case 13: hipLaunchKernelGGL(k_search_pipe<13>, pgrid, block, 0, s, p); return;
+                default: break;
+            }
+        }
         dim3 mgrid((unsigned)p.mgx * rows * p.B);
         switch (p.P) {
             case 3: if (p.chroma) hipLaunchKernelGGL((k_search_mfma<3, true>), mgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_mfma<3, false>), mgrid, block, 0, s, p); return;

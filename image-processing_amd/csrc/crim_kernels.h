@@ -4,6 +4,7 @@
 // reproduce NumPy's results bit for bit, because arg-max / arg-min ties decide which patch is
 // filled next.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <math.h>
 
@@ -1537,6 +1538,291 @@ void k_search_mfma(Params p) {
         p.slist[(size_t)b * p.snx * p.sny + slot] = e;
     }
     STAMP_MID(40);
+}
+
+// Pipelined matrix-core search for engines whose images are all grey.  A block walks down up to
+// p.mtiles consecutive row tiles of one image column; the three planes of a tile (h digits, L,
+// l digits, consumed in that order) travel from global memory straight into a ring of four LDS
+// slots (global_load_lds, no registers in between) while the passes over the previous planes
+// run: the slot a pass has just finished with receives the plane needed three passes later.
+// The tile's window-validity words travel the same way with its first plane.  Template
+// fragments stay in registers for all tiles of the block.
+//
+// Ordering: a plane is published by `s_waitcnt vmcnt(N)` + s_barrier, where N counts only the
+// ring loads certainly issued after it (other outstanding requests make the wait stricter,
+// never looser: vector memory operations retire in order).  The barriers are bare s_barrier
+// instructions (a __syncthreads() would wait for every outstanding load, the ring's included),
+// and the ring loads are issued from inline assembly: the compiler's own bookkeeping of
+// LDS-bound loads makes every later LDS read wait for all of them.
+__device__ __forceinline__ uint32_t lds_address(const void* q) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t*)q;
+}
+// 64 lanes x 16 (4) bytes from per-lane global addresses to LDS bytes [lds, lds + 1024 (256));
+// `lds` is wave-uniform.  M0 is restored: the compiler does not expect it to change.
+__device__ __forceinline__ void gload_lds16(const void* g, uint32_t lds) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds), "v"(g) : "memory");
+}
+__device__ __forceinline__ void gload_lds4(const void* g, uint32_t lds) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds), "v"(g) : "memory");
+}
+// lgkmcnt(0) and vmcnt(N), N <= 63, in the gfx9 encoding (expcnt left at its maximum)
+template <int N>
+__device__ __forceinline__ void publish_barrier() {
+    __builtin_amdgcn_s_waitcnt((N & 15) | 0x70 | ((N >> 4) << 14));
+    __builtin_amdgcn_s_barrier();
+}
+
+#define MSP_SLOT_BYTES (768 * 16)   // 3 chunks of 16 bytes per thread, padded beyond the staged rows
+
+template <int P>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void k_search_pipe(Params p) {
+    constexpr int NS = (P + 1) / 2;
+    constexpr int R = MS_R;
+    constexpr int NF = R + 2 * NS - 2;
+    constexpr int LROWS = MS_ROWS + 2 * NS - 1;
+    constexpr int C16 = MS_PITCH / 16;
+    constexpr int POISON = 1 << 20;
+    static_assert(LROWS * C16 <= 768, "a plane tile is three 16-byte chunks per thread");
+    __shared__ __attribute__((aligned(16))) uint8_t ring[4][MSP_SLOT_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned long long vbits[2][MS_ROWS * 4];
+    __shared__ __attribute__((aligned(16))) uint8_t zl[2][2 * NS][48];
+    __shared__ double s_c[4];
+    __shared__ unsigned s_i[4];
+    __shared__ int s_bound;
+
+    int img_, sub_;
+    xcd_decode(blockIdx.x, p.mgx * p.mchunks, p.B, &img_, &sub_);
+    const int b = p.b0 + img_;
+    const Desc* __restrict__ d = p.desc + b;
+    if (!d->live) return;
+    const int ncy = d->ncy, ncx = d->ncx;
+    const int chunk = sub_ / p.mgx, tbx = sub_ - chunk * p.mgx;
+    const int tb0 = p.sy0 + chunk * p.mtiles;          // first row of tiles of this block
+    const int x0 = tbx * MS_W;
+    if (x0 >= ncx) return;
+    int T = imin(p.mtiles, p.mrows - chunk * p.mtiles);
+    T = imin(T, (ncy - tb0 * MS_ROWS + MS_ROWS - 1) / MS_ROWS);
+    if (T <= 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int H = p.H, W = p.W, Wp = p.Wp;
+    const size_t HW = (size_t)H * W;
+    // everything the pricing needs from the descriptor, read before the first barrier
+    const int clipped = d->clipped;
+    const int chmask = d->chmask & 1;
+    const int soff = d->soff2;
+    const double ph_half = (double)d->ph / 2.0, pw_half = (double)d->pw / 2.0;
+    const double ty = d->ty, tx = d->tx;
+    int bound0 = 0;
+    if (tid == 0) {
+        bound0 = __hip_atomic_load(&p.st[b].bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_bound = bound0;
+    }
+    const uint8_t* inv = p.invalid + (size_t)b * H * p.Wi;
+    const uint8_t* mask = p.mask + b * HW;
+    const int wx = x0 + 64 * (lane >> 4) + (lane & 15);
+
+    // ---- ring loads.  Chunk c = tid + 256 k of a tile is row c / C16, bytes 16 (c % C16) ..;
+    // rows and columns beyond the plane are read from clamped addresses: only windows that are
+    // inadmissible anyway see those bytes.
+    const uint8_t* pl = p.planes + (size_t)b * CRIM_NPL * H * Wp;
+    int crow[3], cgx[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int c = tid + k * 256;
+        crow[k] = c / C16;
+        cgx[k] = imin(x0 + 16 * (c - crow[k] * C16), Wp - 16);
+    }
+    const uint32_t ring_lds = __builtin_amdgcn_readfirstlane(lds_address(&ring[0][0]) + 1024 * wv);
+    const uint32_t vbits_lds = __builtin_amdgcn_readfirstlane(lds_address(&vbits[0][0]) + 256 * wv);
+    auto load_plane = [&](int plane, int tb, int slot) {
+        const uint8_t* src = pl + (size_t)plane * H * Wp;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int gy = imin(tb * MS_ROWS + crow[k], H - 1);
+            gload_lds16(src + (size_t)gy * Wp + cgx[k], ring_lds + slot * MSP_SLOT_BYTES + 4096 * k);
+        }
+    };
+    // validity words of a tile: 32 rows x 4 words, one dword per thread
+    const uint32_t* ivd = (const uint32_t*)(p.invbits + (size_t)b * H * p.Wb + (x0 >> 6)) + (tid & 7);
+    auto load_bits = [&](int tb, int par) {
+        const int gy = imin(tb * MS_ROWS + (tid >> 3), H - 1);
+        gload_lds4(ivd + (size_t)gy * p.Wb * 2, vbits_lds + par * (MS_ROWS * 32));
+    };
+
+    // prologue: the first tile's planes; template rows into LDS
+    load_plane(6, tb0, 0);
+    load_bits(tb0, 0);
+    load_plane(0, tb0, 1);
+    load_plane(5, tb0, 2);
+    constexpr int NZ = 2 * 2 * NS;
+    if (tid < NZ) {
+        const int row = tid % (2 * NS), type = tid / (2 * NS);
+        uint4 zv = make_uint4(0, 0, 0, 0);
+        if (row < P && (type == 1 || chmask)) zv = *(const uint4*)d->zrows[type == 1 ? 3 : 0][row];
+        uint4* z = (uint4*)&zl[0][0][0] + 3 * tid;
+        z[0] = make_uint4(0, 0, 0, 0); z[1] = zv; z[2] = make_uint4(0, 0, 0, 0);
+    }
+
+    const int g = lane >> 4;
+    const int aoff = (wv * R + (g >> 1)) * MS_PITCH + 16 * ((lane & 15) + (g & 1));
+    const int zoff = (g >> 1) * 48 + 16 + 16 * (g & 1) - (lane & 15);
+    auto fragments = [&](int type, v4i* Bf) {
+        const uint8_t* zb = &zl[type][0][0] + (zoff & ~3);
+        const int sh = zoff & 3;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const uint32_t* q = (const uint32_t*)(zb + s * 96);
+            const uint32_t w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3], w4 = q[4];
+            Bf[s][0] = (int)__builtin_amdgcn_alignbyte(w1, w0, sh);
+            Bf[s][1] = (int)__builtin_amdgcn_alignbyte(w2, w1, sh);
+            Bf[s][2] = (int)__builtin_amdgcn_alignbyte(w3, w2, sh);
+            Bf[s][3] = (int)__builtin_amdgcn_alignbyte(w4, w3, sh);
+        }
+    };
+    v4i Bk[NS], Bc[NS];
+    v4i acc[R];
+    auto plane_pass = [&](int slot, const v4i* Bf) {
+        const uint8_t* base = &ring[slot][0] + aoff;
+#pragma unroll
+        for (int r = 0; r < NF; ++r) {
+            const v4i F = *(const v4i*)(base + r * MS_PITCH);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int yy = r - 2 * s;
+                if (yy >= 0 && yy < R)
+                    acc[yy] = __builtin_amdgcn_mfma_i32_16x16x64_i8(F, Bf[s], acc[yy], 0, 0, 0);
+            }
+        }
+    };
+    // the block's lowest cost of a tile is written by thread 0 one barrier after the waves posted theirs
+    auto store_result = [&](int tb) {
+        double bc = s_c[0];
+        unsigned bi = s_i[0];
+        for (int w = 1; w < 4; ++w)
+            if (better_cost(s_c[w], s_i[w], bc, bi)) { bc = s_c[w]; bi = s_i[w]; }
+        SEntry e;
+        e.cost = bc; e.idx = bi; e.pad = 0;
+        p.slist[(size_t)b * p.snx * p.sny + tb * p.snx + tbx] = e;
+    };
+
+    for (int t = 0; t < T; ++t) {
+        // ring slots of this tile's planes; the fourth is free for the next tile's first plane
+        const int sH = (3 * t) & 3, sC = (3 * t + 1) & 3, sE = (3 * t + 2) & 3, sN = (3 * t + 3) & 3;
+        const unsigned long long* vb = vbits[t & 1];
+        const int tb = tb0 + t;
+        const int wy = tb * MS_ROWS + wv * R;
+        const bool more = t + 1 < T;
+
+        publish_barrier<6>();                       // h digits and validity words of this tile
+        if (t > 0 && tid == 0) store_result(tb - 1);
+        if (more) {
+            load_plane(6, tb + 1, sN);
+            load_bits(tb + 1, (t + 1) & 1);
+        }
+        if (t == 0) {
+            fragments(1, Bk);
+            if (chmask) fragments(0, Bc);
+        }
+        // every wave looks at the whole tile's validity words: is there any admissible window?
+        const uint4 q = ((const uint4*)vb)[lane];
+        const bool tile_any = clipped || __ballot((q.x & q.y & q.z & q.w) != 0xffffffffu) != 0;
+        int anyvalid = 0;
+        if (!clipped) {
+            uint32_t all = 0xffffffffu;
+#pragma unroll
+            for (int yy = 0; yy < R; ++yy) {
+                const unsigned long long w = vb[(wv * R + yy) * 4 + g] >> (lane & 15);
+                const uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
+                acc[yy][0] = __builtin_amdgcn_sbfe((int)lo, 0, 1) << 20;
+                acc[yy][1] = __builtin_amdgcn_sbfe((int)lo, 16, 1) << 20;
+                acc[yy][2] = __builtin_amdgcn_sbfe((int)hi, 0, 1) << 20;
+                acc[yy][3] = __builtin_amdgcn_sbfe((int)hi, 16, 1) << 20;
+                all &= lo & hi;
+            }
+            anyvalid = (all & 0x10001u) != 0x10001u;
+        } else {
+            for (int yy = 0; yy < R; ++yy)
+                for (int j = 0; j < 4; ++j) {
+                    const int y = wy + yy, x = wx + 16 * j;
+                    const int ok = (y < ncy && x < ncx && window_valid(p, d, inv, mask, y, x)) ? 1 : 0;
+                    acc[yy][j] = ok ? 0 : -POISON;
+                    anyvalid |= ok;
+                }
+        }
+        const bool wave_on = tile_any && __any(anyvalid);
+        if (wave_on) plane_pass(sH, Bk);
+        if (more) publish_barrier<7>(); else publish_barrier<3>();      // L plane
+        if (more) load_plane(0, tb + 1, sH);
+#pragma unroll
+        for (int yy = 0; yy < R; ++yy) acc[yy] <<= 7;
+        if (wave_on && chmask) plane_pass(sC, Bc);
+        if (more) publish_barrier<7>(); else publish_barrier<0>();      // l digits
+        if (more) load_plane(5, tb + 1, sC);
+#pragma unroll
+        for (int yy = 0; yy < R; ++yy) acc[yy] <<= 1;
+        if (wave_on) plane_pass(sE, Bk);
+
+        // pricing, as in k_search_mfma
+        double bc = INFINITY;
+        unsigned bi = 0xffffffffu;
+        int tmax = -0x7fffffff;
+        if (anyvalid) {
+#pragma unroll
+            for (int yy = 0; yy < R; ++yy)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tmax = imax(tmax, acc[yy][j]);
+        }
+        const int wmax = wave_max_i32(tmax);
+        if (lane == 0 && wmax > -(POISON << 7)) {
+            const long long u = (long long)soff - wmax + p.dmax + 1;
+            if (u < (long long)__hip_atomic_load(&s_bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+                atomicMin(&s_bound, (int)u);
+        }
+        publish_barrier<63>();                      // bounds posted; no ring load is waited for
+        const int ub = __hip_atomic_load(&s_bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const long long lim = (long long)soff - ub;
+        const int thr = lim < -(long long)(POISON << 7) + 1 ? -(POISON << 7) + 1 : (int)lim;
+        if (tmax >= thr) {
+#pragma unroll
+            for (int yy = 0; yy < R; ++yy)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (acc[yy][j] >= thr) {
+                        const int y = wy + yy, x = wx + 16 * j;
+                        // cand_cost with the descriptor fields read up front
+                        const double dy = ((double)y + ph_half) - ty;
+                        const double dx = ((double)x + pw_half) - tx;
+                        const double c = (double)(soff - acc[yy][j]) + sqrt(dy * dy + dx * dx);
+                        const unsigned idx = (unsigned)y * (unsigned)ncx + (unsigned)x;
+                        if (better_cost(c, idx, bc, bi)) { bc = c; bi = idx; }
+                    }
+        }
+        {
+            unsigned long long m = __ballot(bi != 0xffffffffu);
+            double wc = INFINITY;
+            unsigned wi = 0xffffffffu;
+            while (m) {
+                const int l = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const double c = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(bc), l),
+                                                  __builtin_amdgcn_readlane(__double2loint(bc), l));
+                const unsigned i = (unsigned)__builtin_amdgcn_readlane((int)bi, l);
+                if (better_cost(c, i, wc, wi)) { wc = c; wi = i; }
+            }
+            if (lane == 0) { s_c[wv] = wc; s_i[wv] = wi; }
+        }
+    }
+    publish_barrier<0>();
+    if (tid == 0) {
+        store_result(tb0 + T - 1);
+        const int ub = s_bound;
+        if (ub < bound0) atomicMin(&p.st[b].bound, ub);
+    }
 }
 
 // Unspecialised search for any patch edge: one origin at a time, planes read from global

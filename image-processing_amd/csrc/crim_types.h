@@ -96,6 +96,7 @@ struct Params {
     int sy0;      // first block row a search launch covers (split search; 0 otherwise)
     int dmax;     // upper bound of the distance term of the search cost: ceil(sqrt(H^2 + W^2)) + 1
     int mgx, mrows; // matrix-core search launch: blocks per row of tiles, rows of tiles covered
+    int mtiles, mchunks; // pipelined matrix-core search: rows of tiles per block, blocks per column of tiles
     int nparts;   // > 0: split search, k_update reduces xchg[0..nparts) instead of the partial list
     int pgrid;    // priority-scan blocks per image
     int generic;  // use the unspecialised search kernel
