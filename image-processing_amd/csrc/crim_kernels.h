@@ -67,6 +67,7 @@ __device__ __forceinline__ void xcd_decode(unsigned id, int per_image, int nimg,
 
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax_(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t umin_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }
 
 // Cross-lane helpers on the DPP path (no LDS round trip, unlike ds_bpermute-based shuffles).
 // Lane l receives lane l ^ 1 / l ^ 2 of its quad:
@@ -1559,15 +1560,16 @@ __device__ __forceinline__ uint32_t lds_address(const void* q) {
 }
 // 64 lanes x 16 (4) bytes from per-lane global addresses to LDS bytes [lds, lds + 1024 (256));
 // `lds` is wave-uniform.  M0 is restored: the compiler does not expect it to change.
-__device__ __forceinline__ void gload_lds16(const void* g, uint32_t lds) {
+// The global address is a wave-uniform base plus a per-lane unsigned 32-bit byte offset.
+__device__ __forceinline__ void gload_lds16(const void* base, uint32_t off, uint32_t lds) {
     uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "s"(lds), "v"(g) : "memory");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds), "v"(off), "s"(base) : "memory");
 }
-__device__ __forceinline__ void gload_lds4(const void* g, uint32_t lds) {
+__device__ __forceinline__ void gload_lds4(const void* base, uint32_t off, uint32_t lds) {
     uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "s"(lds), "v"(g) : "memory");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds), "v"(off), "s"(base) : "memory");
 }
 // lgkmcnt(0) and vmcnt(N), N <= 63, in the gfx9 encoding (expcnt left at its maximum)
 template <int N>
@@ -1629,36 +1631,44 @@ void k_search_pipe(Params p) {
     // ---- ring loads.  Chunk c = tid + 256 k of a tile is row c / C16, bytes 16 (c % C16) ..;
     // rows and columns beyond the plane are read from clamped addresses: only windows that are
     // inadmissible anyway see those bytes.
+    // inadmissible anyway see those bytes (any address inside the plane will do for them, so the
+    // byte offset of a chunk is simply capped at its column in the plane's last row).  The
+    // offsets are the same for the three planes of a tile and advance by 32 rows per tile.
     const uint8_t* pl = p.planes + (size_t)b * CRIM_NPL * H * Wp;
-    int crow[3], cgx[3];
+    const uint8_t* const plH = pl + (size_t)6 * H * Wp;
+    const uint8_t* const plC = pl;
+    const uint8_t* const plE = pl + (size_t)5 * H * Wp;
+    uint32_t coff[3], cmax[3];    // this tile's chunk offsets, their caps
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const int c = tid + k * 256;
-        crow[k] = c / C16;
-        cgx[k] = imin(x0 + 16 * (c - crow[k] * C16), Wp - 16);
+        const int row = c / C16;
+        const int gx = imin(x0 + 16 * (c - row * C16), Wp - 16);
+        cmax[k] = (uint32_t)(H - 1) * Wp + gx;
+        coff[k] = umin_u32((uint32_t)(tb0 * MS_ROWS + row) * Wp + gx, cmax[k]);
     }
+    const uint32_t tile_step = (uint32_t)MS_ROWS * Wp;
     const uint32_t ring_lds = __builtin_amdgcn_readfirstlane(lds_address(&ring[0][0]) + 1024 * wv);
     const uint32_t vbits_lds = __builtin_amdgcn_readfirstlane(lds_address(&vbits[0][0]) + 256 * wv);
-    auto load_plane = [&](int plane, int tb, int slot) {
-        const uint8_t* src = pl + (size_t)plane * H * Wp;
+    auto load_plane = [&](const uint8_t* src, const uint32_t* off, int slot) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int gy = imin(tb * MS_ROWS + crow[k], H - 1);
-            gload_lds16(src + (size_t)gy * Wp + cgx[k], ring_lds + slot * MSP_SLOT_BYTES + 4096 * k);
-        }
+        for (int k = 0; k < 3; ++k)
+            gload_lds16(src, off[k], ring_lds + slot * MSP_SLOT_BYTES + 4096 * k);
     };
     // validity words of a tile: 32 rows x 4 words, one dword per thread
-    const uint32_t* ivd = (const uint32_t*)(p.invbits + (size_t)b * H * p.Wb + (x0 >> 6)) + (tid & 7);
-    auto load_bits = [&](int tb, int par) {
-        const int gy = imin(tb * MS_ROWS + (tid >> 3), H - 1);
-        gload_lds4(ivd + (size_t)gy * p.Wb * 2, vbits_lds + par * (MS_ROWS * 32));
+    const unsigned long long* ivb = p.invbits + (size_t)b * H * p.Wb;
+    const uint32_t bstep = (uint32_t)p.Wb * 8;
+    const uint32_t bmax = (uint32_t)(H - 1) * bstep + ((x0 >> 6) * 8 + (tid & 7) * 4);
+    uint32_t boff = umin_u32((uint32_t)(tb0 * MS_ROWS + (tid >> 3)) * bstep + ((x0 >> 6) * 8 + (tid & 7) * 4), bmax);
+    auto load_bits = [&](uint32_t off, int par) {
+        gload_lds4(ivb, off, vbits_lds + par * (MS_ROWS * 32));
     };
 
     // prologue: the first tile's planes; template rows into LDS
-    load_plane(6, tb0, 0);
-    load_bits(tb0, 0);
-    load_plane(0, tb0, 1);
-    load_plane(5, tb0, 2);
+    load_plane(plH, coff, 0);
+    load_bits(boff, 0);
+    load_plane(plC, coff, 1);
+    load_plane(plE, coff, 2);
     constexpr int NZ = 2 * 2 * NS;
     if (tid < NZ) {
         const int row = tid % (2 * NS), type = tid / (2 * NS);
@@ -1721,8 +1731,11 @@ void k_search_pipe(Params p) {
         publish_barrier<6>();                       // h digits and validity words of this tile
         if (t > 0 && tid == 0) store_result(tb - 1);
         if (more) {
-            load_plane(6, tb + 1, sN);
-            load_bits(tb + 1, (t + 1) & 1);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) coff[k] = umin_u32(coff[k] + tile_step, cmax[k]);
+            boff = umin_u32(boff + MS_ROWS * bstep, bmax);
+            load_plane(plH, coff, sN);
+            load_bits(boff, (t + 1) & 1);
         }
         if (t == 0) {
             fragments(1, Bk);
@@ -1731,9 +1744,11 @@ void k_search_pipe(Params p) {
         // every wave looks at the whole tile's validity words: is there any admissible window?
         const uint4 q = ((const uint4*)vb)[lane];
         const bool tile_any = clipped || __ballot((q.x & q.y & q.z & q.w) != 0xffffffffu) != 0;
-        int anyvalid = 0;
+        bool wave_any;
         if (!clipped) {
-            uint32_t all = 0xffffffffu;
+            // the wave's 8 rows of words: lanes 0..15 look at 16 bytes each
+            const uint4 qw = ((const uint4*)vb)[wv * 16 + (lane & 15)];
+            wave_any = __ballot((qw.x & qw.y & qw.z & qw.w) != 0xffffffffu) != 0;
 #pragma unroll
             for (int yy = 0; yy < R; ++yy) {
                 const unsigned long long w = vb[(wv * R + yy) * 4 + g] >> (lane & 15);
@@ -1742,10 +1757,9 @@ void k_search_pipe(Params p) {
                 acc[yy][1] = __builtin_amdgcn_sbfe((int)lo, 16, 1) << 20;
                 acc[yy][2] = __builtin_amdgcn_sbfe((int)hi, 0, 1) << 20;
                 acc[yy][3] = __builtin_amdgcn_sbfe((int)hi, 16, 1) << 20;
-                all &= lo & hi;
             }
-            anyvalid = (all & 0x10001u) != 0x10001u;
         } else {
+            int anyvalid = 0;
             for (int yy = 0; yy < R; ++yy)
                 for (int j = 0; j < 4; ++j) {
                     const int y = wy + yy, x = wx + 16 * j;
@@ -1753,16 +1767,17 @@ void k_search_pipe(Params p) {
                     acc[yy][j] = ok ? 0 : -POISON;
                     anyvalid |= ok;
                 }
+            wave_any = __any(anyvalid);
         }
-        const bool wave_on = tile_any && __any(anyvalid);
+        const bool wave_on = tile_any && wave_any;
         if (wave_on) plane_pass(sH, Bk);
         if (more) publish_barrier<7>(); else publish_barrier<3>();      // L plane
-        if (more) load_plane(0, tb + 1, sH);
+        if (more) load_plane(plC, coff, sH);
 #pragma unroll
         for (int yy = 0; yy < R; ++yy) acc[yy] <<= 7;
         if (wave_on && chmask) plane_pass(sC, Bc);
         if (more) publish_barrier<7>(); else publish_barrier<0>();      // l digits
-        if (more) load_plane(5, tb + 1, sC);
+        if (more) load_plane(plE, coff, sC);
 #pragma unroll
         for (int yy = 0; yy < R; ++yy) acc[yy] <<= 1;
         if (wave_on) plane_pass(sE, Bk);
@@ -1770,13 +1785,12 @@ void k_search_pipe(Params p) {
         // pricing, as in k_search_mfma
         double bc = INFINITY;
         unsigned bi = 0xffffffffu;
+        // an inadmissible window ends 2^28 too low, far below any admissible one
         int tmax = -0x7fffffff;
-        if (anyvalid) {
 #pragma unroll
-            for (int yy = 0; yy < R; ++yy)
+        for (int yy = 0; yy < R; ++yy)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) tmax = imax(tmax, acc[yy][j]);
-        }
+            for (int j = 0; j < 4; ++j) tmax = imax(tmax, acc[yy][j]);
         const int wmax = wave_max_i32(tmax);
         if (lane == 0 && wmax > -(POISON << 7)) {
             const long long u = (long long)soff - wmax + p.dmax + 1;
