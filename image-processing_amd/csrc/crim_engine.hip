@@ -229,7 +229,8 @@ static void launch_search(const Params& pin, hipStream_t s, int sy0 = 0, int row
             // pipelined kernel: up to pipe_t rows of tiles per block, fewer when the launch would
             // otherwise have too few blocks to fill the GPU
             int T = std::min(pipe_t, rows);
-            while (T > 1 && (long)p.mgx * ((rows + T - 1) / T) * p.B < 3072) T = (T + 1) / 2;
+            static const long min_blocks = [] { const char* e = getenv("CRIM_PIPE_MIN_BLOCKS"); return e ? atol(e) : 3072L; }();
+            while (T > 1 && (long)p.mgx * ((rows + T - 1) / T) * p.B < min_blocks) T = (T + 1) / 2;
             p.mtiles = T;
             p.mchunks = (rows + T - 1) / T;
             dim3 pgrid((unsigned)p.mgx * p.mchunks * p.B);
@@ -413,7 +414,8 @@ extern "C" int crim_create_batch(int batch, int H, int W, int patch_size, int de
         if (e == hipSuccess) e = hipMalloc(ptr, bytes);
     };
     alloc((void**)&p.bgr, Bz * HW * 3);
-    alloc((void**)&p.planes, Bz * CRIM_NPL * H * p.Wp);
+    // 64 spare rows: the pipelined search reads whole row tiles, also below the last plane's last row
+    alloc((void**)&p.planes, Bz * CRIM_NPL * H * p.Wp + (size_t)64 * p.Wp);
     alloc((void**)&p.mask, Bz * HW);
     alloc((void**)&p.grey, Bz * HW);
     alloc((void**)&p.grad, Bz * HW * sizeof(int));
@@ -437,7 +439,7 @@ extern "C" int crim_create_batch(int batch, int H, int W, int patch_size, int de
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMemcpy(h->d_gamma, t.gamma, sizeof(t.gamma), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(h->d_cbrt, t.cbrt_, sizeof(t.cbrt_), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemset(p.planes, 0, Bz * CRIM_NPL * H * p.Wp);
+    if (e == hipSuccess) e = hipMemset(p.planes, 0, Bz * CRIM_NPL * H * p.Wp + (size_t)64 * p.Wp);
     if (e == hipSuccess) e = hipMemset(p.invalid, 1, Bz * H * p.Wi);
     if (e == hipSuccess) e = hipMemset(p.invbits, 0xff, Bz * H * p.Wb * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(p.st, 0, Bz * sizeof(ImgState));

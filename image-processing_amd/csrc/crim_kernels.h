@@ -1543,9 +1543,9 @@ void k_search_mfma(Params p) {
 
 // Pipelined matrix-core search for engines whose images are all grey.  A block walks down up to
 // p.mtiles consecutive row tiles of one image column; the three planes of a tile (h digits, L,
-// l digits, consumed in that order) travel from global memory straight into a ring of four LDS
-// slots (global_load_lds, no registers in between) while the passes over the previous planes
-// run: the slot a pass has just finished with receives the plane needed three passes later.
+// l digits, consumed in that order) travel from global memory straight into three LDS slots
+// (global_load_lds, no registers in between) while the passes over the other planes run: the
+// slot a pass has just finished with receives the same plane of the next tile.
 // The tile's window-validity words travel the same way with its first plane.  Template
 // fragments stay in registers for all tiles of the block.
 //
@@ -1578,10 +1578,12 @@ __device__ __forceinline__ void publish_barrier() {
     __builtin_amdgcn_s_barrier();
 }
 
-#define MSP_SLOT_BYTES (768 * 16)   // 3 chunks of 16 bytes per thread, padded beyond the staged rows
+#ifndef MSP_WPE
+#define MSP_WPE(P) ((P) > 9 ? 3 : 4)
+#endif
 
 template <int P>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MSP_WPE(P), MSP_WPE(P))))
 void k_search_pipe(Params p) {
     constexpr int NS = (P + 1) / 2;
     constexpr int R = MS_R;
@@ -1589,9 +1591,14 @@ void k_search_pipe(Params p) {
     constexpr int LROWS = MS_ROWS + 2 * NS - 1;
     constexpr int C16 = MS_PITCH / 16;
     constexpr int POISON = 1 << 20;
-    static_assert(LROWS * C16 <= 768, "a plane tile is three 16-byte chunks per thread");
-    __shared__ __attribute__((aligned(16))) uint8_t ring[4][MSP_SLOT_BYTES];
-    __shared__ __attribute__((aligned(16))) unsigned long long vbits[2][MS_ROWS * 4];
+    static_assert(LROWS * C16 <= 768, "a plane tile is at most three 16-byte chunks per thread");
+    // A slot holds whole wave loads (64 chunks).  When the rows end within the third load of wave 2
+    // (patch edges up to 9), wave 3's third load is all padding and goes to `dump` instead.
+    constexpr bool DUMP3 = LROWS * C16 <= 704;
+    constexpr int MSP_SLOT_BYTES = (DUMP3 ? 704 : 768) * 16;
+    __shared__ __attribute__((aligned(16))) uint8_t ring[3][MSP_SLOT_BYTES];
+    __shared__ __attribute__((aligned(16))) uint8_t dump[1024];   // lands the last wave's third chunk
+    __shared__ __attribute__((aligned(16))) unsigned long long vbits[MS_ROWS * 4];
     __shared__ __attribute__((aligned(16))) uint8_t zl[2][2 * NS][48];
     __shared__ double s_c[4];
     __shared__ unsigned s_i[4];
@@ -1629,44 +1636,43 @@ void k_search_pipe(Params p) {
     const int wx = x0 + 64 * (lane >> 4) + (lane & 15);
 
     // ---- ring loads.  Chunk c = tid + 256 k of a tile is row c / C16, bytes 16 (c % C16) ..;
-    // rows and columns beyond the plane are read from clamped addresses: only windows that are
-    // inadmissible anyway see those bytes.
-    // inadmissible anyway see those bytes (any address inside the plane will do for them, so the
-    // byte offset of a chunk is simply capped at its column in the plane's last row).  The
-    // offsets are the same for the three planes of a tile and advance by 32 rows per tile.
+    // columns beyond the plane are read from a clamped address: only windows that are
+    // inadmissible anyway see those bytes.  Rows below the image are read as they come (the next
+    // plane's or image's rows; the buffer ends in spare rows for the last image).  The offsets
+    // are the same for the three planes of a tile and advance by 32 rows per tile.
     const uint8_t* pl = p.planes + (size_t)b * CRIM_NPL * H * Wp;
     const uint8_t* const plH = pl + (size_t)6 * H * Wp;
     const uint8_t* const plC = pl;
     const uint8_t* const plE = pl + (size_t)5 * H * Wp;
-    uint32_t coff[3], cmax[3];    // this tile's chunk offsets, their caps
+    uint32_t coff[3];             // this tile's chunk offsets
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const int c = tid + k * 256;
         const int row = c / C16;
         const int gx = imin(x0 + 16 * (c - row * C16), Wp - 16);
-        cmax[k] = (uint32_t)(H - 1) * Wp + gx;
-        coff[k] = umin_u32((uint32_t)(tb0 * MS_ROWS + row) * Wp + gx, cmax[k]);
+        coff[k] = (uint32_t)(tb0 * MS_ROWS + row) * Wp + gx;
     }
     const uint32_t tile_step = (uint32_t)MS_ROWS * Wp;
     const uint32_t ring_lds = __builtin_amdgcn_readfirstlane(lds_address(&ring[0][0]) + 1024 * wv);
-    const uint32_t vbits_lds = __builtin_amdgcn_readfirstlane(lds_address(&vbits[0][0]) + 256 * wv);
+    const uint32_t vbits_lds = __builtin_amdgcn_readfirstlane(lds_address(&vbits[0]) + 256 * wv);
+    // chunks 704.. (the last wave's third) lie beyond the slot: that wave's load goes to `dump`
+    const bool third_in_slot = __builtin_amdgcn_readfirstlane(!(DUMP3 && wv == 3));
+    const uint32_t third_lds = __builtin_amdgcn_readfirstlane(third_in_slot ? ring_lds + 8192 : lds_address(&dump[0]));
     auto load_plane = [&](const uint8_t* src, const uint32_t* off, int slot) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-            gload_lds16(src, off[k], ring_lds + slot * MSP_SLOT_BYTES + 4096 * k);
+        gload_lds16(src, off[0], ring_lds + slot * MSP_SLOT_BYTES);
+        gload_lds16(src, off[1], ring_lds + slot * MSP_SLOT_BYTES + 4096);
+        gload_lds16(src, off[2], third_lds + (third_in_slot ? slot * MSP_SLOT_BYTES : 0));
     };
     // validity words of a tile: 32 rows x 4 words, one dword per thread
     const unsigned long long* ivb = p.invbits + (size_t)b * H * p.Wb;
     const uint32_t bstep = (uint32_t)p.Wb * 8;
     const uint32_t bmax = (uint32_t)(H - 1) * bstep + ((x0 >> 6) * 8 + (tid & 7) * 4);
     uint32_t boff = umin_u32((uint32_t)(tb0 * MS_ROWS + (tid >> 3)) * bstep + ((x0 >> 6) * 8 + (tid & 7) * 4), bmax);
-    auto load_bits = [&](uint32_t off, int par) {
-        gload_lds4(ivb, off, vbits_lds + par * (MS_ROWS * 32));
-    };
+    auto load_bits = [&](uint32_t off) { gload_lds4(ivb, off, vbits_lds); };
 
     // prologue: the first tile's planes; template rows into LDS
     load_plane(plH, coff, 0);
-    load_bits(boff, 0);
+    load_bits(boff);
     load_plane(plC, coff, 1);
     load_plane(plE, coff, 2);
     constexpr int NZ = 2 * 2 * NS;
@@ -1694,7 +1700,7 @@ void k_search_pipe(Params p) {
             Bf[s][3] = (int)__builtin_amdgcn_alignbyte(w4, w3, sh);
         }
     };
-    v4i Bk[NS], Bc[NS];
+    v4i Bk[NS];
     v4i acc[R];
     auto plane_pass = [&](int slot, const v4i* Bf) {
         const uint8_t* base = &ring[slot][0] + aoff;
@@ -1721,9 +1727,8 @@ void k_search_pipe(Params p) {
     };
 
     for (int t = 0; t < T; ++t) {
-        // ring slots of this tile's planes; the fourth is free for the next tile's first plane
-        const int sH = (3 * t) & 3, sC = (3 * t + 1) & 3, sE = (3 * t + 2) & 3, sN = (3 * t + 3) & 3;
-        const unsigned long long* vb = vbits[t & 1];
+        constexpr int sH = 0, sC = 1, sE = 2;       // ring slots of the three planes
+        const unsigned long long* vb = vbits;
         const int tb = tb0 + t;
         const int wy = tb * MS_ROWS + wv * R;
         const bool more = t + 1 < T;
@@ -1732,15 +1737,10 @@ void k_search_pipe(Params p) {
         if (t > 0 && tid == 0) store_result(tb - 1);
         if (more) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) coff[k] = umin_u32(coff[k] + tile_step, cmax[k]);
+            for (int k = 0; k < 3; ++k) coff[k] += tile_step;
             boff = umin_u32(boff + MS_ROWS * bstep, bmax);
-            load_plane(plH, coff, sN);
-            load_bits(boff, (t + 1) & 1);
         }
-        if (t == 0) {
-            fragments(1, Bk);
-            if (chmask) fragments(0, Bc);
-        }
+        if (t == 0) fragments(1, Bk);
         // every wave looks at the whole tile's validity words: is there any admissible window?
         const uint4 q = ((const uint4*)vb)[lane];
         const bool tile_any = clipped || __ballot((q.x & q.y & q.z & q.w) != 0xffffffffu) != 0;
@@ -1771,13 +1771,22 @@ void k_search_pipe(Params p) {
         }
         const bool wave_on = tile_any && wave_any;
         if (wave_on) plane_pass(sH, Bk);
-        if (more) publish_barrier<7>(); else publish_barrier<3>();      // L plane
-        if (more) load_plane(plC, coff, sH);
+        publish_barrier<3>();                       // L plane; every wave is past the h digits
+        if (more) {
+            load_plane(plH, coff, sH);
+            load_bits(boff);
+        }
 #pragma unroll
         for (int yy = 0; yy < R; ++yy) acc[yy] <<= 7;
-        if (wave_on && chmask) plane_pass(sC, Bc);
-        if (more) publish_barrier<7>(); else publish_barrier<0>();      // l digits
-        if (more) load_plane(plE, coff, sC);
+        if (wave_on && chmask) {
+            // the cross-term fragments are rebuilt for every tile: keeping them would cost 20
+            // registers and the fourth wave per SIMD
+            v4i Bc[NS];
+            fragments(0, Bc);
+            plane_pass(sC, Bc);
+        }
+        if (more) publish_barrier<4>(); else publish_barrier<0>();      // l digits
+        if (more) load_plane(plC, coff, sC);
 #pragma unroll
         for (int yy = 0; yy < R; ++yy) acc[yy] <<= 1;
         if (wave_on) plane_pass(sE, Bk);
@@ -1798,6 +1807,7 @@ void k_search_pipe(Params p) {
                 atomicMin(&s_bound, (int)u);
         }
         publish_barrier<63>();                      // bounds posted; no ring load is waited for
+        if (more) load_plane(plE, coff, sE);
         const int ub = __hip_atomic_load(&s_bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const long long lim = (long long)soff - ub;
         const int thr = lim < -(long long)(POISON << 7) + 1 ? -(POISON << 7) + 1 : (int)lim;
