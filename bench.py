@@ -68,8 +68,9 @@ def pmc_traffic_per_launch(images_per_launch):
     """HBM-side bytes per search launch from the committed rocprofv3 PMC passes of the default
     command (FETCH_SIZE and WRITE_SIZE are collected in separate runs, tools/pmc_passes.sh; they
     cannot be read from inside the benchmark), scaled to this run's images per launch.
-    FETCH_SIZE is doubled: the search stages its tiles with 16-byte-per-lane coalesced loads,
-    which gfx950 tallies at half their bytes.  None when no PMC summary is present."""
+    FETCH_SIZE is doubled: the search stages its tiles with 16-byte-per-lane coalesced loads
+    (straight into LDS), which gfx950 tallies at half their bytes.  None when no PMC summary is
+    present."""
     path = os.path.join(ROOT, "profiles", "pmc_search_latest.json")
     try:
         with open(path) as f:
@@ -242,7 +243,7 @@ def main():
         traffic = pmc_traffic_per_launch(B / 2.0 if B >= 32 else B)
         result["evals_per_s_per_gpu"] = evals / (ms * 1e-3)
         result["roofline"] = {
-            "bound": "hbm", "kernel": "k_search_mfma<9, false>",
+            "bound": "hbm", "kernel": "k_search_pipe<9>",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "avg_launch_us": 1e3 * ms / max(launches, 1), "launches": launches,
@@ -257,7 +258,7 @@ def main():
                     "algorithmic bytes = 3.125 B per pixel per image per iteration (3 byte planes + validity "
                     "bitmap), one launch covers one lane = half the batch; traffic = HBM-side bytes per "
                     "launch from the committed PMC passes (profiles/; FETCH_SIZE doubled for 16-byte "
-                    "loads, plus WRITE_SIZE): tiles overlap by 9 of 41 rows, and the blocks of one image "
+                    "loads, plus WRITE_SIZE): tiles overlap by 8 of 40 rows, every wave load is a whole KiB (10 % padding), and the blocks of one image "
                     "share an XCD so that its L2 serves most of that overlap; mfma_*: integer ops (2 per MAC) against the dense i8 MFMA peak, 243 "
                     "algorithmic MAC per window of 960 issued (each template row occupies 32 K-slots: 16 "
                     "x shifts + 9 taps, padded; two rows per v_mfma_i32_16x16x64_i8)",

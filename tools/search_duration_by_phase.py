@@ -9,14 +9,14 @@ import sys
 
 def main():
     path, per_pass = sys.argv[1], int(sys.argv[2])
-    rows = [r for r in csv.DictReader(open(path)) if 'k_search_mfma' in r['Kernel_Name']]
+    rows = [r for r in csv.DictReader(open(path)) if 'k_search' in r['Kernel_Name']]
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
     d = [int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in rows]
     n = len(d)
     phases = [("graph replays (warm-up + timed steps)", d[:n - 2 * per_pass]),
               ("event pass, each launch alone on the GPU", d[n - 2 * per_pass:n - per_pass]),
               ("event pass, two streams overlapped", d[n - per_pass:])]
-    print("k_search_mfma launches: %d, average %.1f us" % (n, sum(d) / max(n, 1) / 1e3))
+    print("search kernel launches: %d, average %.1f us" % (n, sum(d) / max(n, 1) / 1e3))
     for name, v in phases:
         print("%-45s %5d launches, average %.1f us" % (name, len(v), sum(v) / max(len(v), 1) / 1e3))
 
