@@ -227,9 +227,9 @@ static void launch_search(const Params& pin, hipStream_t s, int sy0 = 0, int row
         static const int pipe_t = [] { const char* e = getenv("CRIM_PIPE_T"); return e ? atoi(e) : 8; }();
         if (!p.chroma && pipe_t > 0) {
             // pipelined kernel: up to pipe_t rows of tiles per block, fewer when the launch would
-            // otherwise have too few blocks to fill the GPU
+            // otherwise have fewer blocks than the GPU holds at once (256 CUs x 4)
             int T = std::min(pipe_t, rows);
-            static const long min_blocks = [] { const char* e = getenv("CRIM_PIPE_MIN_BLOCKS"); return e ? atol(e) : 3072L; }();
+            static const long min_blocks = [] { const char* e = getenv("CRIM_PIPE_MIN_BLOCKS"); return e ? atol(e) : 1024L; }();
             while (T > 1 && (long)p.mgx * ((rows + T - 1) / T) * p.B < min_blocks) T = (T + 1) / 2;
             p.mtiles = T;
             p.mchunks = (rows + T - 1) / T;

@@ -10,7 +10,7 @@ S = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 p = int(sys.argv[2]) if len(sys.argv) > 2 else 9
 ncheck = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 nrun = int(sys.argv[4]) if len(sys.argv) > 4 else 2000
-img = crim_synth.xray_like(S, S, 4000 + S, colour=True)
+img = crim_synth.xray_like(S, S, 4000 + S, colour=os.environ.get("BIG_GREY", "0") != "1")   # BIG_GREY=1: grey engine
 mask = crim_synth.square_hole_mask(S, S, S // 2)
 t = time.time(); oout, oconf, omask, otr, n = c_oracle.run(img, mask, p, max_iters=ncheck); tcpu = time.time() - t
 print("oracle: %d iterations in %.1f s (%.3f s/iter)" % (n, tcpu, tcpu / n), flush=True)
