@@ -224,12 +224,12 @@ static void launch_search(const Params& pin, hipStream_t s, int sy0 = 0, int row
         // SB_H == MS_ROWS: the block rows of both specialised kernels coincide
         p.mgx = (std::max(p.W - p.half, 1) + MS_W - 1) / MS_W;
         p.mrows = rows;
-        static const int pipe_t = [] { const char* e = getenv("CRIM_PIPE_T"); return e ? atoi(e) : 8; }();
+        const int pipe_t = p.pipe_t;
         if (!p.chroma && pipe_t > 0) {
             // pipelined kernel: up to pipe_t rows of tiles per block, fewer when the launch would
             // otherwise have fewer blocks than the GPU holds at once (256 CUs x 4)
             int T = std::min(pipe_t, rows);
-            static const long min_blocks = [] { const char* e = getenv("CRIM_PIPE_MIN_BLOCKS"); return e ? atol(e) : 1024L; }();
+            const long min_blocks = p.pipe_min_blocks;
             while (T > 1 && (long)p.mgx * ((rows + T - 1) / T) * p.B < min_blocks) T = (T + 1) / 2;
             p.mtiles = T;
             p.mchunks = (rows + T - 1) / T;
@@ -405,6 +405,13 @@ extern "C" int crim_create_batch(int batch, int H, int W, int patch_size, int de
     p.sny = (std::max(H - p.half, 1) + SB_H - 1) / SB_H;
     p.generic = ((flags & CRIM_FLAG_GENERIC_SEARCH) || !has_fast_search(p.P)) ? 1 : 0;
     p.dot4 = (flags & CRIM_FLAG_DOT4_SEARCH) ? 1 : 0;
+    {
+        // tuning knobs of the pipelined grey search, read when the engine is created
+        const char* e = getenv("CRIM_PIPE_T");
+        p.pipe_t = e ? atoi(e) : 8;
+        e = getenv("CRIM_PIPE_MIN_BLOCKS");
+        p.pipe_min_blocks = e ? atoi(e) : 1024;
+    }
     p.trace_cap = 0;
     const size_t HW = (size_t)H * W, Bz = (size_t)batch;
     const LabTables& t = lab_tables();

@@ -117,6 +117,60 @@ def test_wide_image_spans_several_search_tiles():
     assert_same_as_oracle(img, m, 7)
 
 
+@pytest.mark.parametrize("p,tiles,H,W,border", [(9, 8, 300, 200, False), (5, 3, 200, 90, True),
+                                              (13, 8, 270, 300, False), (9, 2, 140, 600, True),
+                                              (7, 8, 33, 64, False)])
+def test_pipelined_grey_search_walks_several_row_tiles(p, tiles, H, W, border, monkeypatch):
+    # a single small image would get one row tile per block: force the many-tiles-per-block walk
+    # (chunks of `tiles` rows of tiles, the last chunk shorter, the last tile reaching below the image)
+    monkeypatch.setenv("CRIM_PIPE_MIN_BLOCKS", "1")
+    monkeypatch.setenv("CRIM_PIPE_T", str(tiles))
+    img, m = rand_case(400 + p + tiles, H, W, noise=False, colour=False, border=border)
+    assert_same_as_oracle(img, m, p)
+
+
+def test_pipelined_and_plain_grey_search_agree_on_a_batch(monkeypatch):
+    H, W, B = 96, 80, 16
+    imgs, masks = [], []
+    for i in range(B):
+        img, m = rand_case(430 + i, H, W, noise=(i % 3 == 0), colour=False, border=(i % 4 == 1))
+        imgs.append(img if i % 3 else np.repeat(img[:, :, :1], 3, axis=2))   # noise images made grey
+        masks.append(m)
+    imgs, masks = np.stack(imgs), np.stack(masks)
+    res = []
+    for t in ("0", "8"):
+        monkeypatch.setenv("CRIM_PIPE_T", t)
+        monkeypatch.setenv("CRIM_PIPE_MIN_BLOCKS", "1")
+        with capi.Engine(H, W, 9, batch=B) as eng:
+            eng.upload(imgs, masks)
+            eng.run()
+            out, conf, _ = eng.download(want_conf=True)
+            res.append((out.copy(), conf.copy(), [eng.trace(i).copy() for i in range(B)]))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    for a, b in zip(res[0][2], res[1][2]):
+        assert np.array_equal(a, b)
+    oout, oconf = c_oracle.run(imgs[5], masks[5], 9)[:2]
+    assert np.array_equal(res[1][0][5], oout) and np.array_equal(res[1][1][5], oconf)
+
+
+@pytest.mark.parametrize("flag", [capi.FLAG_PROFILE, capi.FLAG_PROFILE_SOLO])
+def test_profile_flags_count_every_search_launch(flag):
+    H, W, B = 64, 72, 4
+    imgs, masks = zip(*[rand_case(460 + i, H, W, noise=False, colour=(i % 2 == 0)) for i in range(B)])
+    imgs, masks = np.stack(imgs), np.stack(masks)
+    with capi.Engine(H, W, 9, batch=B, flags=flag) as eng:
+        eng.upload(imgs, masks)
+        eng.run()
+        out, _, _ = eng.download()
+        ms, launches, evals = eng.profile()
+        iters = [len(eng.trace(i)) for i in range(B)]
+    for i in range(B):
+        assert np.array_equal(out[i], c_oracle.run(imgs[i], masks[i], 9)[0])
+    # an image is searched once per iteration it takes part in
+    assert evals == float(sum(iters)) * (H - 8) * (W - 8)
+    assert launches >= max(iters) and ms > 0.0
+
+
 # patch_size 1 and 2 give a 1x1 patch around a known pixel: the reference never terminates
 @pytest.mark.parametrize("p", [4, 6, 8, 17, 21, 31])
 def test_generic_patch_sizes(p):
