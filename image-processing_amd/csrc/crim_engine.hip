@@ -225,7 +225,7 @@ static void launch_search(const Params& pin, hipStream_t s, int sy0 = 0, int row
         p.mgx = (std::max(p.W - p.half, 1) + MS_W - 1) / MS_W;
         p.mrows = rows;
         const int pipe_t = p.pipe_t;
-        if (!p.chroma && pipe_t > 0) {
+        if (pipe_t > 0) {
             // pipelined kernel: up to pipe_t rows of tiles per block, fewer when the launch would
             // otherwise have fewer blocks than the GPU holds at once (256 CUs x 4)
             int T = std::min(pipe_t, rows);
@@ -235,12 +235,12 @@ static void launch_search(const Params& pin, hipStream_t s, int sy0 = 0, int row
             p.mchunks = (rows + T - 1) / T;
             dim3 pgrid((unsigned)p.mgx * p.mchunks * p.B);
             switch (p.P) {
-                case 3: hipLaunchKernelGGL(k_search_pipe<3>, pgrid, block, 0, s, p); return;
-                case 5: hipLaunchKernelGGL(k_search_pipe<5>, pgrid, block, 0, s, p); return;
-                case 7: hipLaunchKernelGGL(k_search_pipe<7>, pgrid, block, 0, s, p); return;
-                case 9: hipLaunchKernelGGL(k_search_pipe<9>, pgrid, block, 0, s, p); return;
-                case 11: hipLaunchKernelGGL(k_search_pipe<11>, pgrid, block, 0, s, p); return;
-                case 13: hipLaunchKernelGGL(k_search_pipe<13>, pgrid, block, 0, s, p); return;
+                case 3: if (p.chroma) hipLaunchKernelGGL((k_search_pipe<3, true>), pgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_pipe<3, false>), pgrid, block, 0, s, p); return;
+                case 5: if (p.chroma) hipLaunchKernelGGL((k_search_pipe<5, true>), pgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_pipe<5, false>), pgrid, block, 0, s, p); return;
+                case 7: if (p.chroma) hipLaunchKernelGGL((k_search_pipe<7, true>), pgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_pipe<7, false>), pgrid, block, 0, s, p); return;
+                case 9: if (p.chroma) hipLaunchKernelGGL((k_search_pipe<9, true>), pgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_pipe<9, false>), pgrid, block, 0, s, p); return;
+                case 11: if (p.chroma) hipLaunchKernelGGL((k_search_pipe<11, true>), pgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_pipe<11, false>), pgrid, block, 0, s, p); return;
+                case 13: if (p.chroma) hipLaunchKernelGGL((k_search_pipe<13, true>), pgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_pipe<13, false>), pgrid, block, 0, s, p); return;
                 default: break;
             }
         }

@@ -1541,13 +1541,16 @@ void k_search_mfma(Params p) {
     STAMP_MID(40);
 }
 
-// Pipelined matrix-core search for engines whose images are all grey.  A block walks down up to
-// p.mtiles consecutive row tiles of one image column; the three planes of a tile (h digits, L,
-// l digits, consumed in that order) travel from global memory straight into three LDS slots
-// (global_load_lds, no registers in between) while the passes over the other planes run: the
-// slot a pass has just finished with receives the same plane of the next tile.
-// The tile's window-validity words travel the same way with its first plane.  Template
-// fragments stay in registers for all tiles of the block.
+// Pipelined matrix-core search.  A block walks down up to p.mtiles consecutive row tiles of one
+// image column; the planes of a tile (h digits, L, [a, b,] l digits, consumed in that order: 3
+// for engines whose images are all grey, 5 otherwise) travel from global memory straight into a
+// ring of three LDS slots (global_load_lds, no registers in between) while the passes over the
+// other planes run: the slot a pass has just finished with receives the plane needed three
+// passes later.  The tile's window-validity words travel the same way with its first plane.
+// The template fragments of the k passes stay in registers for all tiles of the block.
+//
+// Load i of the stream (i = planes-per-tile * tile + pass) goes to slot i % 3 and is issued
+// right after the barrier that follows pass i - 3; the barrier before pass i publishes it.
 //
 // Ordering: a plane is published by `s_waitcnt vmcnt(N)` + s_barrier, where N counts only the
 // ring loads certainly issued after it (other outstanding requests make the wait stricter,
@@ -1579,12 +1582,14 @@ __device__ __forceinline__ void publish_barrier() {
 }
 
 #ifndef MSP_WPE
-#define MSP_WPE(P) ((P) > 9 ? 3 : 4)
+#define MSP_WPE(P, CHROMA) (((P) > 9 || ((CHROMA) && (P) > 7)) ? 3 : 4)
 #endif
 
-template <int P>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MSP_WPE(P), MSP_WPE(P))))
+template <int P, bool CHROMA>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MSP_WPE(P, CHROMA), MSP_WPE(P, CHROMA))))
 void k_search_pipe(Params p) {
+    constexpr int NCC = CHROMA ? 3 : 1;         // cross-term channels
+    constexpr int NP = NCC + 2;                 // planes (passes) per tile
     constexpr int NS = (P + 1) / 2;
     constexpr int R = MS_R;
     constexpr int NF = R + 2 * NS - 2;
@@ -1599,7 +1604,7 @@ void k_search_pipe(Params p) {
     __shared__ __attribute__((aligned(16))) uint8_t ring[3][MSP_SLOT_BYTES];
     __shared__ __attribute__((aligned(16))) uint8_t dump[1024];   // lands the last wave's third chunk
     __shared__ __attribute__((aligned(16))) unsigned long long vbits[MS_ROWS * 4];
-    __shared__ __attribute__((aligned(16))) uint8_t zl[2][2 * NS][48];
+    __shared__ __attribute__((aligned(16))) uint8_t zl[NCC + 1][2 * NS][48];
     __shared__ double s_c[4];
     __shared__ unsigned s_i[4];
     __shared__ int s_bound;
@@ -1622,7 +1627,7 @@ void k_search_pipe(Params p) {
     const size_t HW = (size_t)H * W;
     // everything the pricing needs from the descriptor, read before the first barrier
     const int clipped = d->clipped;
-    const int chmask = d->chmask & 1;
+    const int chmask = d->chmask & (CHROMA ? 7 : 1);
     const int soff = d->soff2;
     const double ph_half = (double)d->ph / 2.0, pw_half = (double)d->pw / 2.0;
     const double ty = d->ty, tx = d->tx;
@@ -1639,11 +1644,11 @@ void k_search_pipe(Params p) {
     // columns beyond the plane are read from a clamped address: only windows that are
     // inadmissible anyway see those bytes.  Rows below the image are read as they come (the next
     // plane's or image's rows; the buffer ends in spare rows for the last image).  The offsets
-    // are the same for the three planes of a tile and advance by 32 rows per tile.
+    // are the same for all planes of a tile and advance by 32 rows per tile.
     const uint8_t* pl = p.planes + (size_t)b * CRIM_NPL * H * Wp;
-    const uint8_t* const plH = pl + (size_t)6 * H * Wp;
-    const uint8_t* const plC = pl;
-    const uint8_t* const plE = pl + (size_t)5 * H * Wp;
+    const size_t plane_bytes = (size_t)H * Wp;
+    // plane consumed by pass k of a tile: h digits, L, [a, b,] l digits
+    auto plane_of = [](int k) { return k == 0 ? 6 : (k == NP - 1 ? 5 : k - 1); };
     uint32_t coff[3];             // this tile's chunk offsets
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -1658,7 +1663,8 @@ void k_search_pipe(Params p) {
     // chunks 704.. (the last wave's third) lie beyond the slot: that wave's load goes to `dump`
     const bool third_in_slot = __builtin_amdgcn_readfirstlane(!(DUMP3 && wv == 3));
     const uint32_t third_lds = __builtin_amdgcn_readfirstlane(third_in_slot ? ring_lds + 8192 : lds_address(&dump[0]));
-    auto load_plane = [&](const uint8_t* src, const uint32_t* off, int slot) {
+    auto load_plane = [&](int plane, const uint32_t* off, int slot) {
+        const uint8_t* src = pl + plane * plane_bytes;
         gload_lds16(src, off[0], ring_lds + slot * MSP_SLOT_BYTES);
         gload_lds16(src, off[1], ring_lds + slot * MSP_SLOT_BYTES + 4096);
         gload_lds16(src, off[2], third_lds + (third_in_slot ? slot * MSP_SLOT_BYTES : 0));
@@ -1670,16 +1676,18 @@ void k_search_pipe(Params p) {
     uint32_t boff = umin_u32((uint32_t)(tb0 * MS_ROWS + (tid >> 3)) * bstep + ((x0 >> 6) * 8 + (tid & 7) * 4), bmax);
     auto load_bits = [&](uint32_t off) { gload_lds4(ivb, off, vbits_lds); };
 
-    // prologue: the first tile's planes; template rows into LDS
-    load_plane(plH, coff, 0);
+    // prologue: the first three planes of the first tile; template rows into LDS
+    load_plane(plane_of(0), coff, 0);
     load_bits(boff);
-    load_plane(plC, coff, 1);
-    load_plane(plE, coff, 2);
-    constexpr int NZ = 2 * 2 * NS;
+    load_plane(plane_of(1), coff, 1);
+    load_plane(plane_of(2), coff, 2);
+    constexpr int NZ = (NCC + 1) * 2 * NS;
+    static_assert(NZ <= 256, "one template row per thread");
     if (tid < NZ) {
         const int row = tid % (2 * NS), type = tid / (2 * NS);
         uint4 zv = make_uint4(0, 0, 0, 0);
-        if (row < P && (type == 1 || chmask)) zv = *(const uint4*)d->zrows[type == 1 ? 3 : 0][row];
+        if (row < P && (type == NCC || ((chmask >> type) & 1)))
+            zv = *(const uint4*)d->zrows[type == NCC ? 3 : type][row];
         uint4* z = (uint4*)&zl[0][0][0] + 3 * tid;
         z[0] = make_uint4(0, 0, 0, 0); z[1] = zv; z[2] = make_uint4(0, 0, 0, 0);
     }
@@ -1726,70 +1734,103 @@ void k_search_pipe(Params p) {
         p.slist[(size_t)b * p.snx * p.sny + tb * p.snx + tbx] = e;
     };
 
+    // ring slot of stream load NP * t + i: (tbase + i) % 3 with tbase = (NP * t) % 3
+    int tbase = 0;
+    auto slot_of = [&](int i) {
+        int s = tbase + i % 3;
+        return s >= 3 ? s - 3 : s;
+    };
+    auto publish = [](int n) {   // n is a compile-time constant after unrolling
+        switch (n) {
+            case 0: publish_barrier<0>(); break;
+            case 3: publish_barrier<3>(); break;
+            case 4: publish_barrier<4>(); break;
+            case 6: publish_barrier<6>(); break;
+            default: publish_barrier<63>(); break;
+        }
+    };
     for (int t = 0; t < T; ++t) {
-        constexpr int sH = 0, sC = 1, sE = 2;       // ring slots of the three planes
         const unsigned long long* vb = vbits;
         const int tb = tb0 + t;
         const int wy = tb * MS_ROWS + wv * R;
         const bool more = t + 1 < T;
-
-        publish_barrier<6>();                       // h digits and validity words of this tile
-        if (t > 0 && tid == 0) store_result(tb - 1);
-        if (more) {
+        bool wave_on = false;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) coff[k] += tile_step;
-            boff = umin_u32(boff + MS_ROWS * bstep, bmax);
-        }
-        if (t == 0) fragments(1, Bk);
-        // every wave looks at the whole tile's validity words: is there any admissible window?
-        const uint4 q = ((const uint4*)vb)[lane];
-        const bool tile_any = clipped || __ballot((q.x & q.y & q.z & q.w) != 0xffffffffu) != 0;
-        bool wave_any;
-        if (!clipped) {
-            // the wave's 8 rows of words: lanes 0..15 look at 16 bytes each
-            const uint4 qw = ((const uint4*)vb)[wv * 16 + (lane & 15)];
-            wave_any = __ballot((qw.x & qw.y & qw.z & qw.w) != 0xffffffffu) != 0;
+        for (int j = 0; j < NP; ++j) {
+            // ---- barrier before pass j: load j is waited for, counting the ring loads issued after
+            // it (loads 1 and 2 before pass 0; load j + 1 otherwise, 4 operations when it carries
+            // the next tile's validity words)
+            if (j == 0) publish(6);
+            else if (j + 1 < NP) publish(3);
+            else if (more) publish(4);
+            else publish(0);
+            if (j >= 1) {
+                // pass j - 1 is over in every wave: its slot takes load j + 2
+                const int i = j + 2;
+                if (i < NP) {
+                    load_plane(plane_of(i), coff, slot_of(i));
+                } else if (more) {
+                    if (i == NP) {
 #pragma unroll
-            for (int yy = 0; yy < R; ++yy) {
-                const unsigned long long w = vb[(wv * R + yy) * 4 + g] >> (lane & 15);
-                const uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
-                acc[yy][0] = __builtin_amdgcn_sbfe((int)lo, 0, 1) << 20;
-                acc[yy][1] = __builtin_amdgcn_sbfe((int)lo, 16, 1) << 20;
-                acc[yy][2] = __builtin_amdgcn_sbfe((int)hi, 0, 1) << 20;
-                acc[yy][3] = __builtin_amdgcn_sbfe((int)hi, 16, 1) << 20;
-            }
-        } else {
-            int anyvalid = 0;
-            for (int yy = 0; yy < R; ++yy)
-                for (int j = 0; j < 4; ++j) {
-                    const int y = wy + yy, x = wx + 16 * j;
-                    const int ok = (y < ncy && x < ncx && window_valid(p, d, inv, mask, y, x)) ? 1 : 0;
-                    acc[yy][j] = ok ? 0 : -POISON;
-                    anyvalid |= ok;
+                        for (int k = 0; k < 3; ++k) coff[k] += tile_step;
+                        boff = umin_u32(boff + MS_ROWS * bstep, bmax);
+                    }
+                    load_plane(plane_of(i - NP), coff, slot_of(i));
+                    if (i == NP) load_bits(boff);
                 }
-            wave_any = __any(anyvalid);
-        }
-        const bool wave_on = tile_any && wave_any;
-        if (wave_on) plane_pass(sH, Bk);
-        publish_barrier<3>();                       // L plane; every wave is past the h digits
-        if (more) {
-            load_plane(plH, coff, sH);
-            load_bits(boff);
-        }
+            }
+            if (j == 0) {
+                if (t > 0 && tid == 0) store_result(tb - 1);
+                if (t == 0) fragments(NCC, Bk);
+                // every wave looks at the whole tile's validity words: is there any admissible window?
+                const uint4 q = ((const uint4*)vb)[lane];
+                const bool tile_any = clipped || __ballot((q.x & q.y & q.z & q.w) != 0xffffffffu) != 0;
+                bool wave_any;
+                if (!clipped) {
+                    // the wave's 8 rows of words: lanes 0..15 look at 16 bytes each
+                    const uint4 qw = ((const uint4*)vb)[wv * 16 + (lane & 15)];
+                    wave_any = __ballot((qw.x & qw.y & qw.z & qw.w) != 0xffffffffu) != 0;
 #pragma unroll
-        for (int yy = 0; yy < R; ++yy) acc[yy] <<= 7;
-        if (wave_on && chmask) {
-            // the cross-term fragments are rebuilt for every tile: keeping them would cost 20
-            // registers and the fourth wave per SIMD
-            v4i Bc[NS];
-            fragments(0, Bc);
-            plane_pass(sC, Bc);
-        }
-        if (more) publish_barrier<4>(); else publish_barrier<0>();      // l digits
-        if (more) load_plane(plC, coff, sC);
+                    for (int yy = 0; yy < R; ++yy) {
+                        const unsigned long long w = vb[(wv * R + yy) * 4 + g] >> (lane & 15);
+                        const uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
+                        acc[yy][0] = __builtin_amdgcn_sbfe((int)lo, 0, 1) << 20;
+                        acc[yy][1] = __builtin_amdgcn_sbfe((int)lo, 16, 1) << 20;
+                        acc[yy][2] = __builtin_amdgcn_sbfe((int)hi, 0, 1) << 20;
+                        acc[yy][3] = __builtin_amdgcn_sbfe((int)hi, 16, 1) << 20;
+                    }
+                } else {
+                    int anyvalid = 0;
+                    for (int yy = 0; yy < R; ++yy)
+                        for (int jj = 0; jj < 4; ++jj) {
+                            const int y = wy + yy, x = wx + 16 * jj;
+                            const int ok = (y < ncy && x < ncx && window_valid(p, d, inv, mask, y, x)) ? 1 : 0;
+                            acc[yy][jj] = ok ? 0 : -POISON;
+                            anyvalid |= ok;
+                        }
+                    wave_any = __any(anyvalid);
+                }
+                wave_on = tile_any && wave_any;
+            }
+            // ---- pass j
+            if (j == 1) {
 #pragma unroll
-        for (int yy = 0; yy < R; ++yy) acc[yy] <<= 1;
-        if (wave_on) plane_pass(sE, Bk);
+                for (int yy = 0; yy < R; ++yy) acc[yy] <<= 7;
+            }
+            if (j == NP - 1) {
+#pragma unroll
+                for (int yy = 0; yy < R; ++yy) acc[yy] <<= 1;
+            }
+            if (j == 0 || j == NP - 1) {
+                if (wave_on) plane_pass(slot_of(j), Bk);
+            } else if (wave_on && ((chmask >> (j - 1)) & 1)) {
+                // the cross-term fragments are rebuilt for every tile: keeping them would cost 20
+                // registers per channel and the fourth wave per SIMD
+                v4i Bc[NS];
+                fragments(j - 1, Bc);
+                plane_pass(slot_of(j), Bc);
+            }
+        }
 
         // pricing, as in k_search_mfma
         double bc = INFINITY;
@@ -1807,7 +1848,7 @@ void k_search_pipe(Params p) {
                 atomicMin(&s_bound, (int)u);
         }
         publish_barrier<63>();                      // bounds posted; no ring load is waited for
-        if (more) load_plane(plE, coff, sE);
+        if (more) load_plane(plane_of(2), coff, slot_of(NP + 2));   // the last pass's slot takes load NP + 2
         const int ub = __hip_atomic_load(&s_bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const long long lim = (long long)soff - ub;
         const int thr = lim < -(long long)(POISON << 7) + 1 ? -(POISON << 7) + 1 : (int)lim;
@@ -1840,6 +1881,8 @@ void k_search_pipe(Params p) {
             }
             if (lane == 0) { s_c[wv] = wc; s_i[wv] = wi; }
         }
+        tbase += NP % 3;
+        if (tbase >= 3) tbase -= 3;
     }
     publish_barrier<0>();
     if (tid == 0) {
