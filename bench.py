@@ -114,7 +114,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--batch", type=int, default=8192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--colour", action="store_true",
@@ -243,7 +243,7 @@ def main():
         traffic = pmc_traffic_per_launch(B / 2.0 if B >= 32 else B)
         result["evals_per_s_per_gpu"] = evals / (ms * 1e-3)
         result["roofline"] = {
-            "bound": "hbm", "kernel": "k_search_pipe<9>",
+            "bound": "hbm", "kernel": "k_search_pipe<9, false>",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "avg_launch_us": 1e3 * ms / max(launches, 1), "launches": launches,

@@ -39,7 +39,7 @@ for k, v in summary.items():
         json.dump({"kernel": k, "FETCH_SIZE_KB_per_launch": v["FETCH_SIZE_per_launch"],
                    "WRITE_SIZE_KB_per_launch": v["WRITE_SIZE_per_launch"],
                    "launches": v.get("launches_fetch"),
-                   "images_per_launch": 2048,   # default bench batch 4096 on 2 lanes
+                   "images_per_launch": 4096,   # default bench batch 8192 on 2 lanes
                    "command": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate runs) -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline"},
                   open("$R/gpurun_out/pmc_search_latest.json", "w"), indent=1)
 PY
