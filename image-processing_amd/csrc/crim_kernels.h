@@ -598,12 +598,22 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
         const int tY = tile / p.tnx, tX = tile - tY * p.tnx;
         const int ty0 = tY * CRIM_TILE, tx0 = tX * CRIM_TILE;
         const int ry0 = ty0 - half, rx0 = tx0 - half;
-        uint8_t mv[6];   // MS*MS = 324 <= 6*64
+        // mask grown by one pixel, BORDER_REFLECT_101 beyond the image: two rows of MS columns per
+        // sweep of the wave (lanes 0..31 and 32..63; columns MS.. repeat the last one and are dropped)
+        constexpr int MSW = (MS + 1) / 2;   // sweeps
+        uint8_t mv[MSW];
+        {
+            auto refl = [](int v, int n) {   // reflect101 of v in [-1, ..): -1 -> 1, >= n -> n - 2
+                v = imax(v, -v);
+                v = v >= n ? n - 2 : v;
+                return imax(v, 0);
+            };
+            const unsigned mx = (unsigned)refl(tx0 - 1 + imin(lane & 31, MS - 1), W);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const int i = lane + 64 * k;
-            const int yy = imin(imax(ty0 - 1 + i / MS, -1), H), xx = imin(imax(tx0 - 1 + i % MS, -1), W);
-            mv[k] = mask[(size_t)reflect101(yy, H) * W + reflect101(xx, W)];
+            for (int k = 0; k < MSW; ++k) {
+                const int my = refl(ty0 - 1 + 2 * k + (lane >> 5), H);
+                mv[k] = mask[(unsigned)my * (unsigned)W + mx];
+            }
         }
         // Pixels beyond the image are never read (patches are clipped to it): their records are
         // filled from the clamped position.
@@ -623,10 +633,9 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
             if (first) {
                 first = false;
                 if (tfv <= 0) { stale = true; break; }   // block-uniform
+                if ((lane & 31) < MS) {
 #pragma unroll
-                for (int k = 0; k < 6; ++k) {
-                    const int i = lane + 64 * k;
-                    if (i < MS * MS) s_mask[i] = mv[k];
+                    for (int k = 0; k < MSW; ++k) s_mask[(2 * k + (lane >> 5)) * MS + (lane & 31)] = mv[k];
                 }
             }
 #pragma unroll
