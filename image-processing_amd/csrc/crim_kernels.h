@@ -612,7 +612,7 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
 #pragma unroll
             for (int k = 0; k < MSW; ++k) {
                 const int my = refl(ty0 - 1 + 2 * k + (lane >> 5), H);
-                mv[k] = mask[(unsigned)my * (unsigned)W + mx];
+                mv[k] = mask[__umul24((unsigned)my, (unsigned)W) + mx];
             }
         }
         // Pixels beyond the image are never read (patches are clipped to it): their records are
@@ -626,9 +626,11 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
             for (int k = 0; k < NRB; ++k) {
                 const int row = imin(rb + k * rpp, RS - 1);
                 const int yy = imin(imax(ry0 + row, 0), H - 1);
-                const int idx = yy * W + xx;
-                cv[k] = ccur[idx];
-                gv[k] = grad[idx];
+                // wave-uniform base + 32-bit byte offset (a frame stays far below 2^29 pixels)
+                // (24-bit multiply: one full-rate instruction; H, W < 2^24)
+                const unsigned idx = __umul24((unsigned)yy, (unsigned)W) + (unsigned)xx;
+                cv[k] = *(const double*)((const char*)ccur + (size_t)(idx * 8u));
+                gv[k] = *(const int*)((const char*)grad + (size_t)(idx * 4u));
             }
             if (first) {
                 first = false;
