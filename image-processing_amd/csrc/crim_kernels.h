@@ -1993,8 +1993,10 @@ __global__ __launch_bounds__(256) void k_local_best(Params p, int part, int row0
 
 // PM bounds the patch edge the instance serves: its LDS arrays are sized for it, so the common small
 // patches leave room for many blocks per CU.
+// Patch edges up to 9: eight waves per SIMD (the scalar registers are capped for it), so that 2048
+// blocks, one per image, are resident at once.
 template <int PM>
-__global__ __launch_bounds__(256) void k_update(Params p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PM <= 9 ? 8 : 1, 8))) void k_update(Params p) {
     const int b = p.b0 + blockIdx.x;
     ImgState* st = p.st + b;
     const Desc* __restrict__ d = p.desc + b;
