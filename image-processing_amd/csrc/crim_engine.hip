@@ -241,6 +241,7 @@ static void launch_search(const Params& pin, hipStream_t s, int sy0 = 0, int row
                 case 9: if (p.chroma) hipLaunchKernelGGL((k_search_pipe<9, true>), pgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_pipe<9, false>), pgrid, block, 0, s, p); return;
                 case 11: if (p.chroma) hipLaunchKernelGGL((k_search_pipe<11, true>), pgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_pipe<11, false>), pgrid, block, 0, s, p); return;
                 case 13: if (p.chroma) hipLaunchKernelGGL((k_search_pipe<13, true>), pgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_pipe<13, false>), pgrid, block, 0, s, p); return;
+                case 15: if (p.chroma) hipLaunchKernelGGL((k_search_pipe<15, true>), pgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_pipe<15, false>), pgrid, block, 0, s, p); return;
                 default: break;
             }
         }

@@ -1607,13 +1607,15 @@ void k_search_pipe(Params p) {
     constexpr int LROWS = MS_ROWS + 2 * NS - 1;
     constexpr int C16 = MS_PITCH / 16;
     constexpr int POISON = 1 << 20;
-    static_assert(LROWS * C16 <= 768, "a plane tile is at most three 16-byte chunks per thread");
-    // A slot holds whole wave loads (64 chunks).  When the rows end within the third load of wave 2
-    // (patch edges up to 9), wave 3's third load is all padding and goes to `dump` instead.
-    constexpr bool DUMP3 = LROWS * C16 <= 704;
-    constexpr int MSP_SLOT_BYTES = (DUMP3 ? 704 : 768) * 16;
+    constexpr int NCH = LROWS * C16;            // 16-byte chunks of a plane tile
+    constexpr int NK = (NCH + 255) / 256;       // loads per thread and plane (3, or 4 for patch edge 15)
+    static_assert(NK <= 4, "a plane tile is at most four 16-byte chunks per thread");
+    // A slot holds whole wave loads (64 chunks).  In a thread's last load the waves whose 64 chunks
+    // all lie beyond the tile send them to `dump` instead, so that every wave issues NK loads per plane.
+    constexpr int SLOT_CHUNKS = (NCH + 63) / 64 * 64;
+    constexpr int MSP_SLOT_BYTES = SLOT_CHUNKS * 16;
     __shared__ __attribute__((aligned(16))) uint8_t ring[3][MSP_SLOT_BYTES];
-    __shared__ __attribute__((aligned(16))) uint8_t dump[1024];   // lands the last wave's third chunk
+    __shared__ __attribute__((aligned(16))) uint8_t dump[1024];   // lands the all-padding loads
     __shared__ __attribute__((aligned(16))) unsigned long long vbits[MS_ROWS * 4];
     __shared__ __attribute__((aligned(16))) uint8_t zl[NCC + 1][2 * NS][48];
     __shared__ double s_c[4];
@@ -1660,9 +1662,9 @@ void k_search_pipe(Params p) {
     const size_t plane_bytes = (size_t)H * Wp;
     // plane consumed by pass k of a tile: h digits, L, [a, b,] l digits
     auto plane_of = [](int k) { return k == 0 ? 6 : (k == NP - 1 ? 5 : k - 1); };
-    uint32_t coff[3];             // this tile's chunk offsets
+    uint32_t coff[NK];            // this tile's chunk offsets
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < NK; ++k) {
         const int c = tid + k * 256;
         const int row = c / C16;
         const int gx = imin(x0 + 16 * (c - row * C16), Wp - 16);
@@ -1671,14 +1673,14 @@ void k_search_pipe(Params p) {
     const uint32_t tile_step = (uint32_t)MS_ROWS * Wp;
     const uint32_t ring_lds = __builtin_amdgcn_readfirstlane(lds_address(&ring[0][0]) + 1024 * wv);
     const uint32_t vbits_lds = __builtin_amdgcn_readfirstlane(lds_address(&vbits[0]) + 256 * wv);
-    // chunks 704.. (the last wave's third) lie beyond the slot: that wave's load goes to `dump`
-    const bool third_in_slot = __builtin_amdgcn_readfirstlane(!(DUMP3 && wv == 3));
-    const uint32_t third_lds = __builtin_amdgcn_readfirstlane(third_in_slot ? ring_lds + 8192 : lds_address(&dump[0]));
+    // the last load of a thread: inside the slot, or (this wave's 64 chunks all padding) to `dump`
+    const bool last_in_slot = __builtin_amdgcn_readfirstlane((NK - 1) * 256 + 64 * wv < SLOT_CHUNKS);
+    const uint32_t last_lds = __builtin_amdgcn_readfirstlane(last_in_slot ? ring_lds + 4096 * (NK - 1) : lds_address(&dump[0]));
     auto load_plane = [&](int plane, const uint32_t* off, int slot) {
         const uint8_t* src = pl + plane * plane_bytes;
-        gload_lds16(src, off[0], ring_lds + slot * MSP_SLOT_BYTES);
-        gload_lds16(src, off[1], ring_lds + slot * MSP_SLOT_BYTES + 4096);
-        gload_lds16(src, off[2], third_lds + (third_in_slot ? slot * MSP_SLOT_BYTES : 0));
+#pragma unroll
+        for (int k = 0; k < NK - 1; ++k) gload_lds16(src, off[k], ring_lds + slot * MSP_SLOT_BYTES + 4096 * k);
+        gload_lds16(src, off[NK - 1], last_lds + (last_in_slot ? slot * MSP_SLOT_BYTES : 0));
     };
     // validity words of a tile: 32 rows x 4 words, one dword per thread
     const unsigned long long* ivb = p.invbits + (size_t)b * H * p.Wb;
@@ -1756,7 +1758,9 @@ void k_search_pipe(Params p) {
             case 0: publish_barrier<0>(); break;
             case 3: publish_barrier<3>(); break;
             case 4: publish_barrier<4>(); break;
+            case 5: publish_barrier<5>(); break;
             case 6: publish_barrier<6>(); break;
+            case 8: publish_barrier<8>(); break;
             default: publish_barrier<63>(); break;
         }
     };
@@ -1769,11 +1773,11 @@ void k_search_pipe(Params p) {
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             // ---- barrier before pass j: load j is waited for, counting the ring loads issued after
-            // it (loads 1 and 2 before pass 0; load j + 1 otherwise, 4 operations when it carries
+            // it (loads 1 and 2 before pass 0; load j + 1 otherwise, one more operation when it carries
             // the next tile's validity words)
-            if (j == 0) publish(6);
-            else if (j + 1 < NP) publish(3);
-            else if (more) publish(4);
+            if (j == 0) publish(2 * NK);
+            else if (j + 1 < NP) publish(NK);
+            else if (more) publish(NK + 1);
             else publish(0);
             if (j >= 1) {
                 // pass j - 1 is over in every wave: its slot takes load j + 2
@@ -1783,7 +1787,7 @@ void k_search_pipe(Params p) {
                 } else if (more) {
                     if (i == NP) {
 #pragma unroll
-                        for (int k = 0; k < 3; ++k) coff[k] += tile_step;
+                        for (int k = 0; k < NK; ++k) coff[k] += tile_step;
                         boff = umin_u32(boff + MS_ROWS * bstep, bmax);
                     }
                     load_plane(plane_of(i - NP), coff, slot_of(i));

@@ -117,15 +117,18 @@ def test_wide_image_spans_several_search_tiles():
     assert_same_as_oracle(img, m, 7)
 
 
-@pytest.mark.parametrize("p,tiles,H,W,border", [(9, 8, 300, 200, False), (5, 3, 200, 90, True),
-                                              (13, 8, 270, 300, False), (9, 2, 140, 600, True),
-                                              (7, 8, 33, 64, False)])
-def test_pipelined_grey_search_walks_several_row_tiles(p, tiles, H, W, border, monkeypatch):
+@pytest.mark.parametrize("p,tiles,H,W,border,colour", [
+    (9, 8, 300, 200, False, False), (5, 3, 200, 90, True, False), (13, 8, 270, 300, False, False),
+    (9, 2, 140, 600, True, False), (7, 8, 33, 64, False, False), (15, 4, 210, 120, True, False),
+    (9, 8, 300, 200, False, True), (3, 5, 180, 70, True, True), (11, 3, 200, 280, False, True),
+    (15, 8, 260, 100, False, True)])
+def test_pipelined_search_walks_several_row_tiles(p, tiles, H, W, border, colour, monkeypatch):
     # a single small image would get one row tile per block: force the many-tiles-per-block walk
     # (chunks of `tiles` rows of tiles, the last chunk shorter, the last tile reaching below the image)
     monkeypatch.setenv("CRIM_PIPE_MIN_BLOCKS", "1")
     monkeypatch.setenv("CRIM_PIPE_T", str(tiles))
-    img, m = rand_case(400 + p + tiles, H, W, noise=False, colour=False, border=border)
+    # (three planes per tile for grey images, five for colour ones)
+    img, m = rand_case(400 + p + tiles, H, W, noise=False, colour=colour, border=border)
     assert_same_as_oracle(img, m, p)
 
 
