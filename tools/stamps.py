@@ -21,7 +21,7 @@ acc = {}
 for it in range(20):
     eng.run(max_iters=1)
     st = np.zeros(64, np.int64); lib.crim_debug_stamps(eng._h, st.ctypes.data)
-    for name, slots in (("priority", range(0, 8)), ("select", range(8, 12)), ("update", range(16, 24)), ("search", range(32, 41))):
+    for name, slots in (("priority", (0, 1, 4, 5, 6, 7, 2, 3)), ("select", range(8, 12)), ("update", range(16, 24)), ("search", range(32, 41))):
         v = st[list(slots)]
         d = np.diff(v) * 10  # ns (100 MHz)
         acc.setdefault(name, []).append(d)
