@@ -589,6 +589,7 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
     constexpr int NRB = PT > 0 ? (CRIM_TILE + PT - 1 + 1) / 2 : 16;
     int tile_next = tile_first;
     for (int ti = bx; ti < nt; ti += p.pgrid) {
+        if (ti == bx) STAMP_MID(4);
         const int tile = tile_next;
         // Dependent round trips are what this kernel waits on, so independent loads travel
         // together: the tile's front count (a stale list entry is dropped once it arrives), the
@@ -655,6 +656,7 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
         }
         if (stale) continue;
         __syncthreads();
+        if (ti == bx) STAMP_MID(5);
         int n = 0;
         for (int pass = 0; pass < CRIM_TILE * CRIM_TILE / 64; ++pass) {
             const int pi = pass * 64 + lane;
@@ -669,6 +671,7 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
             n += __popcll(bal);
         }
         __syncthreads();
+        if (ti == bx) STAMP_MID(6);
         View<double> vconf; vconf.base = (const unsigned char*)s_el; vconf.pitch = RS; vconf.oy = ry0; vconf.ox = rx0; vconf.stride = 16;
         View<int> vgrad; vgrad.base = (const unsigned char*)s_el + 12; vgrad.pitch = RS; vgrad.oy = ry0; vgrad.ox = rx0; vgrad.stride = 16;
         for (int e = grp; e < n; e += 64 / PG) {
@@ -725,6 +728,7 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
                 if (better_prio(ev.prio, pos, bestP, bestI)) { bestP = ev.prio; bestI = pos; }
             }
         }
+        if (ti == bx) STAMP_MID(7);
         __syncthreads();   // the staging buffers are reused by the next tile
     }
     STAMP_MID(2);
