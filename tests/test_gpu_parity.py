@@ -132,6 +132,15 @@ def test_pipelined_search_walks_several_row_tiles(p, tiles, H, W, border, colour
     assert_same_as_oracle(img, m, p)
 
 
+@pytest.mark.parametrize("p,colour,border", [(9, True, False), (15, True, True), (5, False, True),
+                                             (13, True, False)])
+def test_plain_matrix_core_search_kernel(p, colour, border, monkeypatch):
+    # CRIM_PIPE_T=0 selects the non-pipelined kernel (register-staged tiles, one tile per block)
+    monkeypatch.setenv("CRIM_PIPE_T", "0")
+    img, m = rand_case(480 + p, 90, 300, noise=False, colour=colour, border=border)
+    assert_same_as_oracle(img, m, p)
+
+
 def test_pipelined_and_plain_grey_search_agree_on_a_batch(monkeypatch):
     H, W, B = 96, 80, 16
     imgs, masks = [], []
