@@ -34,6 +34,8 @@ class Criminisi_Inpainter():
         Pixels values: 1 for missing, 0 for known region.
     '''
 
+    VERBOSE_CHUNK = 64   # iterations between two bursts of verbose output
+
     def __init__(self, image, mask, patch_size=9, verbose=False, show_progress=False, device=0):
         self.image = image
         self.mask = mask.round()
@@ -93,8 +95,24 @@ class Criminisi_Inpainter():
         self._engine = eng
         eng.upload(img, mask_u8)
 
-        if self.verbose or self.show_progress:
-            # Per-iteration side effects need the host in the loop: one iteration per call.
+        if self.verbose and not self.show_progress:
+            # The per-iteration lines (:67-69, :76-77) are printed for a chunk of iterations at a
+            # time from the device's per-iteration records, so that the fill loop keeps replaying
+            # graphs; 'Time to find best' is the chunk's wall time divided by its iterations.
+            shown = 0
+            while True:
+                chunk_start = time.time()
+                _, remaining = eng.run(max_iters=self.VERBOSE_CHUNK)
+                recs = eng.trace(0)
+                per_iter = (time.time() - chunk_start) / max(len(recs) - shown, 1)
+                for r in recs[shown:]:
+                    print('Time to find best: %.2f seconds' % per_iter)
+                    print('%d of %d completed' % (total - int(r['remaining']), total))
+                shown = len(recs)
+                if remaining == 0:
+                    break
+        elif self.show_progress:
+            # A frame before every iteration's update needs the host in the loop: one iteration per call.
             c = 0
             while True:
                 if self.show_progress:

@@ -361,6 +361,29 @@ def test_shim_class_end_to_end():
     assert ip.front.shape == (64, 64) and not ip.front.any()
 
 
+def test_shim_verbose_and_show_progress_side_effects(tmp_path, monkeypatch, capsys):
+    # verbose: the reference's lines per iteration (:67-69, :76-77, :85-87), printed in chunks;
+    # show_progress: results/working_image_<c>.png before every iteration's update (:55-57)
+    from src.criminisi_inpainter import Criminisi_Inpainter
+    img = crim_synth.xray_like(48, 56, 902, colour=True)
+    m = crim_synth.blob_mask(48, 56, 902, fraction=0.05, margin=9)
+    oout, _, _, otr, n = c_oracle.run(img, m, 9)
+    total = int(m.sum())
+    monkeypatch.setattr(Criminisi_Inpainter, "VERBOSE_CHUNK", 3)
+    out = Criminisi_Inpainter(img, m, patch_size=9, verbose=True).inpaint()
+    assert np.array_equal(out, oout)
+    lines = capsys.readouterr().out.splitlines()
+    assert len(lines) == 2 * n + 1
+    assert all(l.startswith('Time to find best: ') and l.endswith(' seconds') for l in lines[0:-1:2])
+    assert lines[1:-1:2] == ['%d of %d completed' % (total - int(r), total) for r in otr['remaining']]
+    assert lines[-1].startswith('Inpainting took ')
+    monkeypatch.chdir(tmp_path)
+    os.makedirs('results')
+    out = Criminisi_Inpainter(img, m, patch_size=9, show_progress=True).inpaint()
+    assert np.array_equal(out, oout)
+    assert sorted(os.listdir('results')) == sorted('working_image_%d.png' % c for c in range(n))
+
+
 def test_full_size_properties_256():
     """BASELINE configs[1] shape: 256x256 grey image, 10 % mask, patch 9 -- oracle parity plus
     size-independent properties (known pixels untouched, every filled pixel is a copy of a
