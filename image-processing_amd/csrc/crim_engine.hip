@@ -435,7 +435,13 @@ extern "C" int crim_create_batch(int batch, int H, int W, int patch_size, int de
     alloc((void**)&p.tlist, Bz * p.tcap * sizeof(int));
     alloc((void**)&p.st, Bz * sizeof(ImgState));
     alloc((void**)&p.desc, Bz * sizeof(Desc));
-    p.pgrid = std::min(std::min(2048, p.tnx * p.tny), std::max(16, 16384 / batch));
+    // priority waves per image: a wave's fixed cost (state, set-up: about 3 us) is shared by the tiles it
+    // walks, so large batches, which fill the GPU anyway, get few waves per image
+    p.pgrid = std::min(std::min(2048, p.tnx * p.tny), std::max(8, 16384 / batch));
+    if (const char* e = getenv("CRIM_PGRID")) {   // tuning knob: priority waves per image
+        const int g = atoi(e);
+        if (g > 0) p.pgrid = std::min(g, p.tnx * p.tny);
+    }
     p.b0 = 0;
     alloc((void**)&p.plist, Bz * p.pgrid * sizeof(PEntry));
     alloc((void**)&p.slist, Bz * p.snx * p.sny * sizeof(SEntry));
