@@ -278,8 +278,8 @@ static void launch_compact(const Params& p, hipStream_t s) {
 
 static size_t priority_lds_bytes(const Params& p) {
     const size_t rs = CRIM_TILE + 2 * p.half;
-    // records, front list, mask, per-lane offset table (4 x 15 pairs), alignment slack
-    return rs * rs * 16 + CRIM_TILE * CRIM_TILE * 4 + (CRIM_TILE + 2) * (CRIM_TILE + 2) + 4 * 15 * 8 + 24;
+    // records, front list (bytes), mask, per-lane offset table (4 x 15 pairs of 16-bit offsets), alignment slack
+    return rs * rs * 16 + CRIM_TILE * CRIM_TILE + (CRIM_TILE + 2) * (CRIM_TILE + 2) + 4 * 15 * 4 + 8;
 }
 
 static void launch_update(const Params& p, hipStream_t s) {

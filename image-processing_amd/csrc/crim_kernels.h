@@ -545,8 +545,9 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
     const int RS = PT > 0 ? CRIM_TILE + PT - 1 : CRIM_TILE + 2 * half;   // edge of the staged region
     constexpr int MS = CRIM_TILE + 2;                                    // edge of the staged mask
     uint4* s_el = (uint4*)smem;
-    int* s_list = (int*)(s_el + RS * RS);
-    uint8_t* s_mask = (uint8_t*)(s_list + CRIM_TILE * CRIM_TILE);
+    // (byte and 16-bit entries: at patch edge 9 the block then fits 10 KB, 16 waves per CU)
+    uint8_t* s_list = (uint8_t*)(s_el + RS * RS);   // tile-local pixel index, < 256
+    uint8_t* s_mask = s_list + CRIM_TILE * CRIM_TILE;
     const int* tl = p.tlist + (size_t)b * p.tcap;
     const int* tf = p.tfront + (size_t)b * p.tnx * p.tny;
     const double* ccur = p.conf + ((size_t)b * 2 + cur) * HW;
@@ -561,11 +562,12 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
     // per-lane-of-group table of record offsets (LDS, not registers: the registers buy a fourth
     // wave per SIMD): s_off[l][2i + k] = byte offset of flattened element 8i + 2l + k
     constexpr int NE = PT > 0 ? (PT * PT) / 8 : 1;
-    int2* s_off = (int2*)(((uintptr_t)(s_mask + MS * MS) + 7) & ~(uintptr_t)7);
+    static_assert(CRIM_TILE * CRIM_TILE <= 256, "tile-local pixel indices are bytes");
+    ushort2* s_off = (ushort2*)(((uintptr_t)(s_mask + MS * MS) + 3) & ~(uintptr_t)3);
     if (PT > 0) {
         for (int t = lane; t < PG * NE; t += 64) {
             const int ll = t / NE, i = t - ll * NE;
-            int2 o;
+            ushort2 o;
             {
                 const int e = 8 * i + 2 * ll;
                 const int row = e / (PT > 0 ? PT : 1), col = e - row * PT;
@@ -667,7 +669,7 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
                 isf = m0[MS + 1] == 0 && (m0[0] + m0[2] + m0[2 * MS] + m0[2 * MS + 2]) > 0;
             }
             const unsigned long long bal = __ballot(isf);
-            if (isf) s_list[n + __popcll(bal & ((1ull << lane) - 1ull))] = pi;
+            if (isf) s_list[n + __popcll(bal & ((1ull << lane) - 1ull))] = (uint8_t)pi;
             n += __popcll(bal);
         }
         __syncthreads();
@@ -693,7 +695,7 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
                 const unsigned kb = 1023u - 2u * (unsigned)l;
 #pragma unroll 5
                 for (int i = 0; i < NE; ++i) {
-                    const int2 o = s_off[l * NE + i];
+                    const ushort2 o = s_off[l * NE + i];
                     const uint4 a = *(const uint4*)(eb + o.x);
                     const uint4 c = *(const uint4*)(eb + o.y);
                     const double ca = __hiloint2double((int)a.y, (int)a.x);
