@@ -502,7 +502,10 @@ static int init_images(crim_engine* h, int first, int count) {
     const Params& p = h->prm;
     hipLaunchKernelGGL(k_init_state, dim3((count + 63) / 64), dim3(64), 0, h->stream, p, first, count);
     dim3 grid(p.tnx, p.tny, count), block(256);
-    hipLaunchKernelGGL(k_init_pixels, grid, block, 0, h->stream, p, first);
+    {
+        const size_t HW = (size_t)p.H * p.W;
+        hipLaunchKernelGGL(k_init_pixels, dim3((unsigned)((HW + 1023) / 1024), count), block, 0, h->stream, p, first);
+    }
     hipLaunchKernelGGL(k_init_fields, grid, block, 0, h->stream, p, first);
     HIP_TRY(hipGetLastError());
     for (int i = 0; i < count; ++i) h->uploaded[first + i] = true;

@@ -345,34 +345,83 @@ __global__ __launch_bounds__(256) void k_build_mask(Params p, int first, int thr
     p.mask[b * HW + (size_t)y * p.W + x] = (uint8_t)m;
 }
 
-// One block per 16x16 tile: normalises the mask to {0,1}, derives confidence, grey and the
-// search planes and counts the masked pixels.
+// Normalises the mask to {0,1}, derives confidence, grey and the search planes and counts the
+// masked pixels.  Every array but the planes is a plain [H*W] vector, so a thread takes four
+// consecutive pixels of the flattened image (1024 per block): dword mask / grey / plane accesses
+// and 32-byte confidence stores instead of single bytes.  Four pixels stay in one row, and their
+// plane bytes in one aligned dword, when W is a multiple of 4; other widths go pixel by pixel.
 __global__ __launch_bounds__(256) void k_init_pixels(Params p, int first) {
-    const int b = first + blockIdx.z;
-    const int y = blockIdx.y * CRIM_TILE + (threadIdx.x >> 4);
-    const int x = blockIdx.x * CRIM_TILE + (threadIdx.x & 15);
+    const int b = first + blockIdx.y;
     const size_t HW = (size_t)p.H * p.W;
-    int m = 0, chroma = 0;
-    if (y < p.H && x < p.W) {
-        const size_t i = (size_t)y * p.W + x;
-        uint8_t* mk = p.mask + b * HW;
-        m = mk[i] ? 1 : 0;
-        mk[i] = (uint8_t)m;
-        const double c = 1.0 - (double)m;
-        p.conf[(b * 2 + 0) * HW + i] = c;
-        p.conf[(b * 2 + 1) * HW + i] = c;
-        const uint8_t* px = p.bgr + (b * HW + i) * 3;
-        const int B_ = px[0], G_ = px[1], R_ = px[2];
-        p.grey[b * HW + i] = (uint8_t)((B_ * 3735 + G_ * 19235 + R_ * 9798 + 16384) >> 15);
-        uint8_t pl[CRIM_NPL];
+    const size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    uint8_t* mk = p.mask + b * HW;
+    const uint8_t* bgr = p.bgr + b * HW * 3;
+    uint8_t* grey = p.grey + b * HW;
+    double* c0 = p.conf + (b * 2 + 0) * HW;
+    double* c1 = p.conf + (b * 2 + 1) * HW;
+    uint8_t* planes = p.planes + (size_t)b * CRIM_NPL * p.H * p.Wp;
+    const size_t PS = (size_t)p.H * p.Wp;
+    int cnt = 0, chroma = 0;
+    auto one = [&](int B_, int G_, int R_, uint8_t pl[CRIM_NPL]) -> uint8_t {
         lab_planes(p, B_, G_, R_, pl);
-        uint8_t* base = p.planes + (size_t)b * CRIM_NPL * p.H * p.Wp + (size_t)y * p.Wp + x;
-        for (int k = 0; k < CRIM_NPL; ++k) base[(size_t)k * p.H * p.Wp] = pl[k];
-        chroma = (pl[1] | pl[2]) ? 1 : 0;
+        chroma |= (pl[1] | pl[2]) ? 1 : 0;
+        return (uint8_t)((B_ * 3735 + G_ * 19235 + R_ * 9798 + 16384) >> 15);
+    };
+    if ((p.W & 3) == 0 && i0 + 4 <= HW) {
+        const uint32_t m4 = *(const uint32_t*)(mk + i0);
+        const uint32_t q0 = *(const uint32_t*)(bgr + 3 * i0), q1 = *(const uint32_t*)(bgr + 3 * i0 + 4),
+                       q2 = *(const uint32_t*)(bgr + 3 * i0 + 8);
+        const uint8_t px[12] = {(uint8_t)q0, (uint8_t)(q0 >> 8), (uint8_t)(q0 >> 16), (uint8_t)(q0 >> 24),
+                                (uint8_t)q1, (uint8_t)(q1 >> 8), (uint8_t)(q1 >> 16), (uint8_t)(q1 >> 24),
+                                (uint8_t)q2, (uint8_t)(q2 >> 8), (uint8_t)(q2 >> 16), (uint8_t)(q2 >> 24)};
+        uint32_t mo = 0, go = 0, po[CRIM_NPL] = {0, 0, 0, 0, 0, 0, 0};
+        double cv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = ((m4 >> (8 * j)) & 0xffu) ? 1 : 0;
+            cnt += m;
+            mo |= (uint32_t)m << (8 * j);
+            cv[j] = 1.0 - (double)m;
+            uint8_t pl[CRIM_NPL];
+            go |= (uint32_t)one(px[3 * j], px[3 * j + 1], px[3 * j + 2], pl) << (8 * j);
+#pragma unroll
+            for (int k2 = 0; k2 < CRIM_NPL; ++k2) po[k2] |= (uint32_t)pl[k2] << (8 * j);
+        }
+        *(uint32_t*)(mk + i0) = mo;
+        *(uint32_t*)(grey + i0) = go;
+        *(double2*)(c0 + i0) = make_double2(cv[0], cv[1]);
+        *(double2*)(c0 + i0 + 2) = make_double2(cv[2], cv[3]);
+        *(double2*)(c1 + i0) = make_double2(cv[0], cv[1]);
+        *(double2*)(c1 + i0 + 2) = make_double2(cv[2], cv[3]);
+        const size_t y = i0 / p.W, x = i0 - y * p.W;
+#pragma unroll
+        for (int k2 = 0; k2 < CRIM_NPL; ++k2) *(uint32_t*)(planes + k2 * PS + y * p.Wp + x) = po[k2];
+    } else {
+        for (int j = 0; j < 4; ++j) {
+            const size_t i = i0 + j;
+            if (i >= HW) break;
+            const int m = mk[i] ? 1 : 0;
+            cnt += m;
+            mk[i] = (uint8_t)m;
+            const double c = 1.0 - (double)m;
+            c0[i] = c;
+            c1[i] = c;
+            uint8_t pl[CRIM_NPL];
+            grey[i] = one(bgr[3 * i], bgr[3 * i + 1], bgr[3 * i + 2], pl);
+            const size_t y = i / p.W, x = i - y * p.W;
+            for (int k2 = 0; k2 < CRIM_NPL; ++k2) planes[k2 * PS + y * p.Wp + x] = pl[k2];
+        }
     }
-    const int cnt = __syncthreads_count(m);
-    if (threadIdx.x == 0 && cnt) atomicAdd(&p.st[b].remaining, cnt);
-    if (__syncthreads_or(chroma) && threadIdx.x == 0) atomicOr(&p.st[b].chroma, 1);
+    // block totals: wave sums by a shuffle tree, one atomic per block
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
+    __shared__ int s_cnt[4];
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = cnt;
+    const int any_chroma = __syncthreads_or(chroma);
+    if (threadIdx.x == 0) {
+        const int total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        if (total) atomicAdd(&p.st[b].remaining, total);
+        if (any_chroma) atomicOr(&p.st[b].chroma, 1);
+    }
 }
 
 // Gradient field, window-validity map and the per-tile count of front pixels; needs the
