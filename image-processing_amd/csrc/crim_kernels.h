@@ -436,6 +436,21 @@ __global__ __launch_bounds__(256) void k_init_fields(Params p, int first) {
     // tx0 + j masked or beyond the image), by wave ballots; a window is inadmissible when the OR of
     // its P rows has a bit set among its P columns.
     __shared__ unsigned long long s_rowbits[CRIM_TILE + CRIM_PMAX - 1];
+    // the tile grown by one pixel: the mask with BORDER_REFLECT_101 (front weight), and the grey
+    // values with masked pixels read as 0 (gradient; positions beyond the image are never used)
+    constexpr int TS = CRIM_TILE + 2;
+    __shared__ uint8_t s_mk[TS * TS], s_gg[TS * TS];
+    {
+        const int tx0 = blockIdx.x * CRIM_TILE, ty0 = blockIdx.y * CRIM_TILE;
+        const uint8_t* gr = p.grey + b * HW;
+        for (int e = threadIdx.x; e < TS * TS; e += 256) {
+            const int i = e / TS, j = e - i * TS;
+            const int yy = imin(imax(ty0 - 1 + i, -1), p.H), xx = imin(imax(tx0 - 1 + j, -1), p.W);
+            s_mk[e] = mk[(size_t)reflect101(yy, p.H) * p.W + reflect101(xx, p.W)];
+            const size_t q = (size_t)imin(imax(yy, 0), p.H - 1) * p.W + imin(imax(xx, 0), p.W - 1);
+            s_gg[e] = mk[q] ? (uint8_t)0 : gr[q];
+        }
+    }
     {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const int tx0 = blockIdx.x * CRIM_TILE, ty0 = blockIdx.y * CRIM_TILE;
@@ -452,15 +467,29 @@ __global__ __launch_bounds__(256) void k_init_fields(Params p, int first) {
     __syncthreads();
     int isfront = 0, inv_bit = 1;
     if (y < p.H && x < p.W) {
-        p.grad[b * HW + (size_t)y * p.W + x] = grad_packed(p.grey + b * HW, mk, p.H, p.W, y, x);
         const int py = threadIdx.x >> 4, px = threadIdx.x & 15;
+        {
+            // np.gradient (:174): central differences, one-sided at the image border (grad_packed)
+            const uint8_t* g0 = s_gg + (py + 1) * TS + (px + 1);
+            const int H = p.H, W = p.W;
+            int gy2, gx2;
+            if (H == 1) gy2 = 0;
+            else if (y == 0) gy2 = 2 * ((int)g0[TS] - (int)g0[0]);
+            else if (y == H - 1) gy2 = 2 * ((int)g0[0] - (int)g0[-TS]);
+            else gy2 = (int)g0[TS] - (int)g0[-TS];
+            if (W == 1) gx2 = 0;
+            else if (x == 0) gx2 = 2 * ((int)g0[1] - (int)g0[0]);
+            else if (x == W - 1) gx2 = 2 * ((int)g0[0] - (int)g0[-1]);
+            else gx2 = (int)g0[1] - (int)g0[-1];
+            p.grad[b * HW + (size_t)y * p.W + x] = (gy2 & 0xffff) | (int)((unsigned)gx2 << 16);
+        }
         unsigned long long rows = 0;
         for (int i = 0; i < p.P; ++i) rows |= s_rowbits[py + i];
         const int inv = ((rows >> px) & ((1ull << p.P) - 1ull)) != 0;
         p.invalid[((size_t)b * p.H + y) * p.Wi + x] = (uint8_t)inv;
         inv_bit = inv;
-        int nb[9];
-        isfront = front_weight(mk, p.H, p.W, y, x, nb) > 0;
+        const uint8_t* m0 = s_mk + py * TS + px;   // top-left of the 3x3 neighbourhood
+        isfront = m0[TS + 1] == 0 && (m0[0] + m0[2] + m0[2 * TS] + m0[2 * TS + 2]) > 0;
     }
     {
         // bitmap form: a wave covers 4 tile rows of 16 origins; origins beyond the image stay 1
