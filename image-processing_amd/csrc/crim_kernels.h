@@ -1669,6 +1669,13 @@ __device__ __forceinline__ void gload_lds4(const void* base, uint32_t off, uint3
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, %3\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(lds), "v"(off), "s"(base) : "memory");
 }
+// Bit `pos` of w as 0 or -1 in one instruction (hipcc expands the one-bit signed field extract into
+// an and, a subtraction and shifts).
+__device__ __forceinline__ int sbit_field(uint32_t w, int pos) {
+    int r;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(r) : "v"(w), "n"(pos));
+    return r;
+}
 // lgkmcnt(0) and vmcnt(N), N <= 63, in the gfx9 encoding (expcnt left at its maximum)
 template <int N>
 __device__ __forceinline__ void publish_barrier() {
@@ -1893,10 +1900,10 @@ void k_search_pipe(Params p) {
                     for (int yy = 0; yy < R; ++yy) {
                         const unsigned long long w = vb[(wv * R + yy) * 4 + g] >> (lane & 15);
                         const uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
-                        acc[yy][0] = __builtin_amdgcn_sbfe((int)lo, 0, 1) << 20;
-                        acc[yy][1] = __builtin_amdgcn_sbfe((int)lo, 16, 1) << 20;
-                        acc[yy][2] = __builtin_amdgcn_sbfe((int)hi, 0, 1) << 20;
-                        acc[yy][3] = __builtin_amdgcn_sbfe((int)hi, 16, 1) << 20;
+                        acc[yy][0] = sbit_field(lo, 0) << 20;
+                        acc[yy][1] = sbit_field(lo, 16) << 20;
+                        acc[yy][2] = sbit_field(hi, 0) << 20;
+                        acc[yy][3] = sbit_field(hi, 16) << 20;
                     }
                 } else {
                     int anyvalid = 0;
