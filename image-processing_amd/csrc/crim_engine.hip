@@ -145,6 +145,7 @@ struct Lane {
     Params prm;                     // engine parameters with b0 / B narrowed to this lane
     std::vector<GraphSet> graphs;
     long done = 0;                  // iterations launched in the current crim_run call
+    long last = 0;                  // iterations launched in the previous round of that call
 };
 
 struct crim_engine {
@@ -158,6 +159,7 @@ struct crim_engine {
     uint16_t* d_cbrt = nullptr;
     ImgState* h_state = nullptr;    // pinned mirror of prm.st
     std::vector<bool> uploaded;
+    std::vector<int> prev_remaining;   // per image: masked pixels left at the previous round of crim_run
     bool prepared = false;          // scan window, trace buffer and graphs match the uploads
     // profile accumulators
     std::vector<hipEvent_t> ev;     // pairs
@@ -738,7 +740,8 @@ extern "C" int crim_run(crim_t* h, long max_iters, long* iters_done, long* remai
     const bool profile = (h->flags & CRIM_FLAG_PROFILE) != 0;
     const bool eager = (h->flags & CRIM_FLAG_EAGER) != 0;
     const bool solo = (h->flags & CRIM_FLAG_PROFILE_SOLO) != 0;
-    for (auto& ln : h->lanes) ln.done = 0;
+    for (auto& ln : h->lanes) { ln.done = 0; ln.last = 0; }
+    h->prev_remaining.assign((size_t)p.B, -1);
     int rc = CRIM_OK;
     if (h->split_parts > 0) {
         const int r2 = run_split(h, max_iters);
@@ -756,14 +759,23 @@ extern "C" int crim_run(crim_t* h, long max_iters, long* iters_done, long* remai
         for (auto& ln : h->lanes) {
             const Params& lp = ln.prm;
             long need = 0, live = 0;
+            double est = 0.0;   // iterations the slowest image still needs at the rate of the last round
             for (int i = lp.b0; i < lp.b0 + lp.B; ++i) {
                 const ImgState& s = h->h_state[i];
-                if (!s.live) continue;
+                if (!s.live) { h->prev_remaining[i] = 0; continue; }
                 ++live;
                 // every iteration fills at most P*P pixels: a lower bound on what is still needed
                 const long lb = std::max(1L, ((long)s.remaining + p.P * p.P - 1) / (p.P * p.P));
                 need = std::max(need, lb);
+                const int filled = h->prev_remaining[i] - s.remaining;
+                if (ln.last > 0 && h->prev_remaining[i] >= 0 && filled > 0)
+                    est = std::max(est, (double)s.remaining * (double)ln.last / (double)filled);
+                h->prev_remaining[i] = s.remaining;
             }
+            // Rounds end in a host round trip with the lanes drained, so they should be few: most of
+            // the extrapolated need is launched at once (an image that finishes early only makes the
+            // rest of its iterations empty launches); the lower bound keeps the first round honest.
+            if (!profile && !eager) need = std::max(need, (long)(0.85 * est));
             if (live == 0) continue;
             if (max_iters > 0) need = std::min(need, max_iters - ln.done);
             if (need <= 0) continue;
@@ -814,6 +826,7 @@ extern "C" int crim_run(crim_t* h, long max_iters, long* iters_done, long* remai
                     }
                 ln.done += need;
             }
+            ln.last = need;
         }
         HIP_TRY(hipGetLastError());
         if (!any) break;
