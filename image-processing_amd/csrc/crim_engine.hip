@@ -772,10 +772,11 @@ extern "C" int crim_run(crim_t* h, long max_iters, long* iters_done, long* remai
                     est = std::max(est, (double)s.remaining * (double)ln.last / (double)filled);
                 h->prev_remaining[i] = s.remaining;
             }
-            // Rounds end in a host round trip with the lanes drained, so they should be few: most of
-            // the extrapolated need is launched at once (an image that finishes early only makes the
+            // Rounds end in a host round trip with the lanes drained, so they should be few: the
+            // extrapolated need is launched at once (an image that finishes early only makes the
             // rest of its iterations empty launches); the lower bound keeps the first round honest.
-            if (!profile && !eager) need = std::max(need, (long)(0.85 * est));
+            // (measured: extrapolation factors 0.6 ... 1.5 are within 0.5 % of each other)
+            if (!profile && !eager) need = std::max(need, (long)est);
             if (live == 0) continue;
             if (max_iters > 0) need = std::min(need, max_iters - ln.done);
             if (need <= 0) continue;
