@@ -2149,7 +2149,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PM <= 9 ? 8
     const int mg = P - 1 > 2 ? P - 1 : 2;   // margin of the mask snapshot around the patch
     const int mr0 = r0 - mg, mc0 = c0 - mg;
     const int mrh = ph + 2 * mg, mrw = pw + 2 * mg;
-    // Every load of this round is unconditional, from a position clamped into the image, and the
+    // Every load of this batch is unconditional, from a position clamped into the image, and the
     // out-of-image value is selected afterwards: the requests of a batch travel together.
     constexpr int NMB = (MR * MR + 255) / 256 < 8 ? (MR * MR + 255) / 256 : 8;   // mask loads per batch
     constexpr int NGB = (GR * GR + 255) / 256;
