@@ -2114,7 +2114,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PM <= 9 ? 8
     __shared__ unsigned long long s_rw[MR][2];         // OR of P consecutive rows
 
     // The kernel is a chain of dependent memory round trips, so independent loads are issued
-    // together.  Round 1: loop state, descriptor, and the partial arg-min list (read up to its
+    // together.  Load batch 1: loop state, descriptor, and the partial arg-min list (read up to its
     // capacity; entries beyond the count are ignored once the count has arrived).
     const SEntry* sl = p.nparts > 0 ? p.xchg : p.slist + (size_t)b * p.snx * p.sny;
     const int cap = p.nparts > 0 ? p.nparts : p.snx * p.sny;
@@ -2144,7 +2144,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PM <= 9 ? 8
     const size_t PS = (size_t)H * p.Wp;
     double* cnxt = p.conf + ((size_t)b * 2 + (cur ^ 1)) * HW;
 
-    // Round 2 (needs only the descriptor): the mask around the patch, the grey values around it,
+    // Load batch 2 (needs only the descriptor): the mask around the patch, the grey values around it,
     // and the fresh confidence of the pixels within one pixel of the patch.
     const int mg = P - 1 > 2 ? P - 1 : 2;   // margin of the mask snapshot around the patch
     const int mr0 = r0 - mg, mc0 = c0 - mg;
@@ -2251,7 +2251,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PM <= 9 ? 8
     STAMP(17);
     const int sy = (int)(s_src / (unsigned)ncx), sx = (int)(s_src % (unsigned)ncx);
 
-    // Round 3 (needs the source position): the source pixels.
+    // Load batch 3 (needs the source position): the source pixels.
     for (int e = tid; e < ph * pw; e += 256) {
         const int i = e / pw, j = e - i * pw;
         const size_t s = (size_t)(sy + i) * W + sx + j;
