@@ -86,7 +86,8 @@ def _cpu_one(args):
     img, mask = args
     t = time.time()
     out, conf, msk, tr, n = c_oracle.run(img, mask, PATCH, want_trace=False)
-    return time.time() - t, n
+    import zlib
+    return time.time() - t, n, zlib.crc32(out.tobytes())
 
 
 def cpu_baseline(imgs, masks, budget_images_per_core=4):
@@ -103,7 +104,8 @@ def cpu_baseline(imgs, masks, budget_images_per_core=4):
         res = pool.map(_cpu_one, tasks)
     wall = time.time() - t0
     iters = sum(r[1] for r in res)
-    return {"value": n / wall, "unit": "images/s", "cores": cores, "kind": "port",
+    return {"_crc": [r[2] for r in res],
+            "value": n / wall, "unit": "images/s", "cores": cores, "kind": "port",
             "sample": "%d of the batch's 256x256 images (first by index), C oracle "
                       "oracle/criminisi_oracle.c, one image per process, %d processes; "
                       "%.1f s wall, %d iterations" % (n, cores, wall, iters)}
@@ -264,6 +266,12 @@ def main():
                     "x shifts + 9 taps, padded; two rows per v_mfma_i32_16x16x64_i8)",
         }
     if cpu is not None:
+        # the sample's outputs double as a check of the timed run's results (outside the timed region)
+        import zlib
+        crcs = cpu.pop("_crc")
+        got, _, _ = eng.download(0, len(crcs))
+        same = sum(int(zlib.crc32(got[i].tobytes()) == c) for i, c in enumerate(crcs))
+        cpu["outputs_identical_to_gpu"] = "%d of %d" % (same, len(crcs))
         result["cpu_baseline"] = cpu
     eng.close()
     if rank == 0:
