@@ -25,6 +25,7 @@ FLAG_PROFILE = 2
 FLAG_GENERIC_SEARCH = 4
 FLAG_DOT4_SEARCH = 8
 FLAG_PROFILE_SOLO = 16
+FLAG_NO_TRACE = 32
 
 MAX_PATCH = 31
 

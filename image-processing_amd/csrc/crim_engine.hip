@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -117,11 +118,8 @@ void build_lab_tables(LabTables& t) {
 
 const LabTables& lab_tables() {
     static LabTables t;
-    static bool built = false;
-    if (!built) {
-        build_lab_tables(t);
-        built = true;
-    }
+    static std::once_flag once;
+    std::call_once(once, [] { build_lab_tables(t); });
     return t;
 }
 
@@ -185,7 +183,9 @@ struct RcclApi {
     decltype(&ncclGetErrorString) error_string = nullptr;
 };
 RcclApi g_rccl;
+std::mutex g_rccl_mutex;
 int load_rccl() {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
     if (g_rccl.lib) return CRIM_OK;
     void* lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
     if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
@@ -334,6 +334,44 @@ static int build_graph(Lane& ln, int iters, GraphSet* out) {
     return CRIM_OK;
 }
 
+// Everything of Params that follows from the shape alone (no device memory).
+static void init_geometry(Params& p, int batch, int H, int W, int patch_size, unsigned flags) {
+    memset(&p, 0, sizeof(p));
+    p.B = batch; p.H = H; p.W = W;
+    p.half = (patch_size - 1) / 2;
+    p.P = 2 * p.half + 1;
+    p.psq = patch_size * patch_size;
+    p.ND = (p.P + 6) / 4;
+    p.Wp = round_up(W + 16, 16);
+    p.Wi = round_up(W, 4) + 4;
+    p.Wb = 4 * ((W + MS_W - 1) / MS_W);
+    p.dmax = (int)std::ceil(std::sqrt((double)H * H + (double)W * W)) + 1;
+    p.tnx = (W + CRIM_TILE - 1) / CRIM_TILE;
+    p.tny = (H + CRIM_TILE - 1) / CRIM_TILE;
+    p.tcap = 2 * p.tnx * p.tny;
+    // the candidate grid is largest for the most clipped patch: (H - half) x (W - half)
+    p.snx = (std::max(W - p.half, 1) + SB_W - 1) / SB_W;
+    p.sny = (std::max(H - p.half, 1) + SB_H - 1) / SB_H;
+    p.generic = ((flags & CRIM_FLAG_GENERIC_SEARCH) || !has_fast_search(p.P)) ? 1 : 0;
+    p.dot4 = (flags & CRIM_FLAG_DOT4_SEARCH) ? 1 : 0;
+    {
+        // tuning knobs of the pipelined grey search, read when the engine is created
+        const char* e = getenv("CRIM_PIPE_T");
+        p.pipe_t = e ? atoi(e) : 8;
+        e = getenv("CRIM_PIPE_MIN_BLOCKS");
+        p.pipe_min_blocks = e ? atoi(e) : 1024;
+    }
+    // priority waves per image: a wave's fixed cost (state, set-up: about 3 us) is shared by the tiles it
+    // walks, so large batches, which fill the GPU anyway, get few waves per image
+    p.pgrid = std::min(std::min(2048, p.tnx * p.tny), std::max(8, 16384 / batch));
+    if (const char* e = getenv("CRIM_PGRID")) {   // tuning knob: priority waves per image
+        const int g = atoi(e);
+        if (g > 0) p.pgrid = std::min(g, p.tnx * p.tny);
+    }
+    p.b0 = 0;
+    p.trace_cap = 0;
+}
+
 extern "C" int crim_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -360,7 +398,8 @@ extern "C" void crim_destroy(crim_t* h) {
     if (h->comm && g_rccl.comm_destroy) (void)g_rccl.comm_destroy(h->comm);
     for (auto& ln : h->lanes)
         if (ln.stream) (void)hipStreamDestroy(ln.stream);
-    for (auto e : h->ev) (void)hipEventDestroy(e);
+    for (auto e : h->ev)
+        if (e) (void)hipEventDestroy(e);
     Params& p = h->prm;
     void* bufs[] = {p.bgr, p.planes, p.mask, p.grey, p.grad, p.conf, p.invalid, p.invbits, p.tfront, p.tlist, p.st,
                     p.desc, p.plist, p.slist, p.xchg, p.trace, p.dbg, h->d_gamma, h->d_cbrt, h->d_peek};
@@ -391,31 +430,7 @@ extern "C" int crim_create_batch(int batch, int H, int W, int patch_size, int de
     if (h->flags & CRIM_FLAG_PROFILE) h->flags |= CRIM_FLAG_EAGER;
     h->patch_size = patch_size;
     Params& p = h->prm;
-    memset(&p, 0, sizeof(p));
-    p.B = batch; p.H = H; p.W = W;
-    p.half = (patch_size - 1) / 2;
-    p.P = 2 * p.half + 1;
-    p.psq = patch_size * patch_size;
-    p.ND = (p.P + 6) / 4;
-    p.Wp = round_up(W + 16, 16);
-    p.Wi = round_up(W, 4) + 4;
-    p.Wb = 4 * ((W + MS_W - 1) / MS_W);
-    p.dmax = (int)std::ceil(std::sqrt((double)H * H + (double)W * W)) + 1;
-    p.tnx = (W + CRIM_TILE - 1) / CRIM_TILE;
-    p.tny = (H + CRIM_TILE - 1) / CRIM_TILE;
-    // the candidate grid is largest for the most clipped patch: (H - half) x (W - half)
-    p.snx = (std::max(W - p.half, 1) + SB_W - 1) / SB_W;
-    p.sny = (std::max(H - p.half, 1) + SB_H - 1) / SB_H;
-    p.generic = ((flags & CRIM_FLAG_GENERIC_SEARCH) || !has_fast_search(p.P)) ? 1 : 0;
-    p.dot4 = (flags & CRIM_FLAG_DOT4_SEARCH) ? 1 : 0;
-    {
-        // tuning knobs of the pipelined grey search, read when the engine is created
-        const char* e = getenv("CRIM_PIPE_T");
-        p.pipe_t = e ? atoi(e) : 8;
-        e = getenv("CRIM_PIPE_MIN_BLOCKS");
-        p.pipe_min_blocks = e ? atoi(e) : 1024;
-    }
-    p.trace_cap = 0;
+    init_geometry(p, batch, H, W, patch_size, flags);
     const size_t HW = (size_t)H * W, Bz = (size_t)batch;
     const LabTables& t = lab_tables();
     memcpy(p.coef, t.coef, sizeof(p.coef));
@@ -432,19 +447,10 @@ extern "C" int crim_create_batch(int batch, int H, int W, int patch_size, int de
     alloc((void**)&p.conf, Bz * 2 * HW * sizeof(double));
     alloc((void**)&p.invalid, Bz * H * p.Wi);
     alloc((void**)&p.invbits, Bz * H * p.Wb * sizeof(unsigned long long));
-    p.tcap = 2 * p.tnx * p.tny;
     alloc((void**)&p.tfront, Bz * p.tnx * p.tny * sizeof(int));
     alloc((void**)&p.tlist, Bz * p.tcap * sizeof(int));
     alloc((void**)&p.st, Bz * sizeof(ImgState));
     alloc((void**)&p.desc, Bz * sizeof(Desc));
-    // priority waves per image: a wave's fixed cost (state, set-up: about 3 us) is shared by the tiles it
-    // walks, so large batches, which fill the GPU anyway, get few waves per image
-    p.pgrid = std::min(std::min(2048, p.tnx * p.tny), std::max(8, 16384 / batch));
-    if (const char* e = getenv("CRIM_PGRID")) {   // tuning knob: priority waves per image
-        const int g = atoi(e);
-        if (g > 0) p.pgrid = std::min(g, p.tnx * p.tny);
-    }
-    p.b0 = 0;
     alloc((void**)&p.plist, Bz * p.pgrid * sizeof(PEntry));
     alloc((void**)&p.slist, Bz * p.snx * p.sny * sizeof(SEntry));
     alloc((void**)&p.dbg, 64 * sizeof(long long));
@@ -480,7 +486,7 @@ extern "C" int crim_create_batch(int batch, int H, int W, int patch_size, int de
         h->lanes.resize(nl);
         for (int i = 0; i < nl; ++i) {
             Lane& ln = h->lanes[i];
-            HIP_TRY(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking);
             ln.prm = p;
             ln.prm.b0 = (int)((long)batch * i / nl);
             ln.prm.B = (int)((long)batch * (i + 1) / nl) - ln.prm.b0;
@@ -489,7 +495,14 @@ extern "C" int crim_create_batch(int batch, int H, int W, int patch_size, int de
     if (h->flags & CRIM_FLAG_PROFILE) {
         h->ev.resize(2 * 64);
         h->ev_evals.resize(64);
-        for (auto& ev : h->ev) HIP_TRY(hipEventCreate(&ev));
+        for (auto& ev : h->ev) ev = nullptr;
+        for (auto& ev : h->ev)
+            if (e == hipSuccess) e = hipEventCreate(&ev);
+    }
+    if (e != hipSuccess) {
+        const int code = fail(CRIM_ERR_HIP, "crim_create: %s", hipGetErrorString(e));
+        crim_destroy(h);
+        return code;
     }
     *out = h;
     return CRIM_OK;
@@ -500,15 +513,17 @@ extern "C" int crim_create(int H, int W, int patch_size, int device, unsigned fl
 }
 
 // Derives every cached field of images [first, first+count) from prm.bgr / prm.mask.
+static void launch_init(const Params& p, hipStream_t s, int first, int count) {
+    hipLaunchKernelGGL(k_init_state, dim3((count + 63) / 64), dim3(64), 0, s, p, first, count);
+    dim3 grid(p.tnx, p.tny, count), block(256);
+    const size_t HW = (size_t)p.H * p.W;
+    hipLaunchKernelGGL(k_init_pixels, dim3((unsigned)((HW + 1023) / 1024), count), block, 0, s, p, first);
+    hipLaunchKernelGGL(k_init_fields, grid, block, 0, s, p, first);
+}
+
 static int init_images(crim_engine* h, int first, int count) {
     const Params& p = h->prm;
-    hipLaunchKernelGGL(k_init_state, dim3((count + 63) / 64), dim3(64), 0, h->stream, p, first, count);
-    dim3 grid(p.tnx, p.tny, count), block(256);
-    {
-        const size_t HW = (size_t)p.H * p.W;
-        hipLaunchKernelGGL(k_init_pixels, dim3((unsigned)((HW + 1023) / 1024), count), block, 0, h->stream, p, first);
-    }
-    hipLaunchKernelGGL(k_init_fields, grid, block, 0, h->stream, p, first);
+    launch_init(p, h->stream, first, count);
     HIP_TRY(hipGetLastError());
     for (int i = 0; i < count; ++i) h->uploaded[first + i] = true;
     h->prepared = false;
@@ -598,11 +613,20 @@ static int prepare(crim_engine* h) {
     for (int i = 0; i < p.B; ++i) need = std::max(need, (long)h->h_state[i].remaining + 1);
     q.chroma = 0;
     for (int i = 0; i < p.B; ++i) q.chroma |= h->h_state[i].chroma ? 1 : 0;
-    if (need > p.trace_cap || !p.trace) {
+    if (!(h->flags & CRIM_FLAG_NO_TRACE) && (need > p.trace_cap || !p.trace)) {
         if (p.trace) HIP_TRY(hipFree(p.trace));
         q.trace = nullptr;
         p.trace = nullptr;
-        HIP_TRY(hipMalloc((void**)&q.trace, (size_t)p.B * need * sizeof(crim_iter_rec)));
+        q.trace_cap = 0;
+        p.trace_cap = 0;
+        const hipError_t te = hipMalloc((void**)&q.trace, (size_t)p.B * need * sizeof(crim_iter_rec));
+        if (te != hipSuccess) {
+            q.trace = nullptr;
+            return fail(te == hipErrorOutOfMemory ? CRIM_ERR_NOMEM : CRIM_ERR_HIP,
+                        "crim_run: per-iteration records (%ld per image, %d images): %s; "
+                        "create the engine with CRIM_FLAG_NO_TRACE to run without them",
+                        need, p.B, hipGetErrorString(te));
+        }
         q.trace_cap = need;
     }
     const bool changed = memcmp(&q, &p, sizeof(Params)) != 0;
@@ -946,6 +970,18 @@ extern "C" int crim_debug_stamps(crim_t* h, long long* out64) {
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpy(out64, h->prm.dbg, 64 * sizeof(long long), hipMemcpyDeviceToHost));
+    return CRIM_OK;
+}
+
+// Diagnostic: raw copy of image `index`'s loop state (16 ints: iter, live, cur, remaining, tcount,
+// chroma, pcount, scount, stalled, bound, rebuilds, ...).  Not part of the public header.
+extern "C" int crim_debug_state(crim_t* h, int index, int* out16) {
+    if (!h || !out16) return fail(CRIM_ERR_ARG, "crim_debug_state: null argument");
+    if (index < 0 || index >= h->prm.B) return fail(CRIM_ERR_ARG, "crim_debug_state: index %d of %d", index, h->prm.B);
+    static_assert(sizeof(ImgState) == 16 * sizeof(int), "ImgState is 16 ints");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(out16, h->prm.st + index, sizeof(ImgState), hipMemcpyDeviceToHost));
     return CRIM_OK;
 }
 

@@ -515,6 +515,7 @@ __global__ void k_init_state(Params p, int first, int count) {
     s->iter = 0; s->live = 1; s->cur = 0; s->remaining = 0;
     s->tcount = 0; s->chroma = 0;
     s->pcount = 0; s->scount = 0; s->stalled = 0; s->bound = 0x7fffffff;
+    s->rebuilds = 0;
     p.desc[first + i].live = 0;
 }
 
@@ -606,7 +607,9 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
     // the waves per image, so the read is in bounds; it is used only when bx < tcount)
     const int tile_first = p.tlist[(size_t)b * p.tcap + bx];
     const int live = st->live;
-    const int nt = (int)st->tcount;
+    // (k_update rebuilds a list that outgrew its capacity before this kernel runs again; the clamp
+    // only keeps a reader inside the list whatever the count says)
+    const int nt = imin((int)st->tcount, p.tcap);
     const int cur = st->cur;
     if (!live) return;
     const int H = p.H, W = p.W, half = p.half;
@@ -2112,6 +2115,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PM <= 9 ? 8
     __shared__ unsigned s_fill[(PM * PM + 31) / 32];   // bit e: patch element e was filled
     __shared__ unsigned long long s_rb[MR][2];         // per snapshot row: bit j = pixel j masked
     __shared__ unsigned long long s_rw[MR][2];         // OR of P consecutive rows
+    __shared__ int s_ovf;                              // the tile list outgrew its capacity
+    __shared__ unsigned s_tw[4];
 
     // The kernel is a chain of dependent memory round trips, so independent loads are issued
     // together.  Load batch 1: loop state, descriptor, and the partial arg-min list (read up to its
@@ -2237,7 +2242,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PM <= 9 ? 8
         if (better_cost(oc, oi, bc, bi)) { bc = oc; bi = oi; }
     }
     if ((tid & 63) == 0) { s_c[tid >> 6] = bc; s_i[tid >> 6] = bi; }
-    if (tid == 0) s_filled = 0;
+    if (tid == 0) { s_filled = 0; s_ovf = 0; }
     if (tid < (PM * PM + 31) / 32) s_fill[tid] = 0;
     __syncthreads();
     if (tid == 0) {
@@ -2380,6 +2385,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PM <= 9 ? 8
                 if (atomicAdd(&tf[tile], 1) == 0) {
                     const unsigned k = atomicAdd(&st->tcount, 1u);
                     if (k < (unsigned)p.tcap) tl[k] = tile;
+                    else s_ovf = 1;   // dropped: the list is rebuilt from the counts below
                 }
             } else {
                 atomicSub(&tf[tile], 1);
@@ -2430,6 +2436,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PM <= 9 ? 8
         grad[(size_t)yy * W + xx] = (gy2 & 0xffff) | (int)((unsigned)gx2 << 16);
     }
     STAMP(22);
+    // ---- tile list: entries are only ever appended between rebuilds (k_tiles runs in the long graphs
+    // alone), so a list that would outgrow its capacity is rebuilt here, from the exact counts, in
+    // row-major tile order.  This block is the only writer of its image's counts and list.
+    __syncthreads();
+    if (s_ovf) {
+        const int lane = tid & 63, wv = tid >> 6;
+        const int nt = p.tnx * p.tny;
+        int* tf = p.tfront + (size_t)b * nt;
+        int* tl = p.tlist + (size_t)b * p.tcap;
+        unsigned base = 0;
+        for (int t0 = 0; t0 < nt; t0 += 256) {
+            const int t = t0 + tid;
+            // (the counts were last changed by this block's atomics: read them where those landed)
+            const bool on = t < nt && __hip_atomic_load(&tf[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0;
+            const unsigned long long bal = __ballot(on);
+            if (lane == 0) s_tw[wv] = (unsigned)__popcll(bal);
+            __syncthreads();
+            unsigned off = base;
+            for (int w = 0; w < wv; ++w) off += s_tw[w];
+            if (on) tl[off + __popcll(bal & ((1ull << lane) - 1ull))] = t;
+            base += s_tw[0] + s_tw[1] + s_tw[2] + s_tw[3];
+            __syncthreads();
+        }
+        if (tid == 0) {
+            st->tcount = base;
+            st->rebuilds += 1;
+        }
+    }
     // ---- loop state and trace
     if (tid == 0) {
         const int nf = s_filled;

@@ -37,7 +37,8 @@ struct ImgState {
     unsigned scount; // entries in this image's search partial list
     int stalled;     // an iteration filled nothing while pixels remained
     int bound;       // running upper bound on floor(best cost) for search pruning
-    int pad[6];
+    int rebuilds;    // times k_update rebuilt a tile list that had outgrown its capacity
+    int pad[5];
 };
 
 // Best front pixel of one priority tile.

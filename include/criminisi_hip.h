@@ -56,8 +56,10 @@ enum {
     CRIM_FLAG_GENERIC_SEARCH = 4u, /* use the unspecialised search kernel for every patch size */
     CRIM_FLAG_DOT4_SEARCH = 8u,    /* use the vector dot-product search kernel instead of the
                                       matrix-core one (patch sizes 3..16) */
-    CRIM_FLAG_PROFILE_SOLO = 16u   /* as CRIM_FLAG_PROFILE, but every bracketed search launch has the
+    CRIM_FLAG_PROFILE_SOLO = 16u,  /* as CRIM_FLAG_PROFILE, but every bracketed search launch has the
                                       GPU to itself (the stream is drained after each iteration) */
+    CRIM_FLAG_NO_TRACE = 32u       /* keep no per-iteration records (crim_trace then returns none):
+                                      saves 32 bytes per image and possible iteration */
 };
 
 /* Largest patch_size accepted.  The reference takes any integer (:18); the bit-exact regime

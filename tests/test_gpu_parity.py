@@ -302,6 +302,49 @@ def test_fields_match_numpy_oracle_mid_run():
             assert np.array_equal(msk[0], o.working_mask)
 
 
+def _debug_state(eng, index=0):
+    import ctypes
+    buf = (ctypes.c_int * 16)()
+    rc = capi.load_library().crim_debug_state(eng._h, int(index), buf)
+    assert rc == 0
+    return list(buf)
+
+
+@pytest.mark.parametrize("side,seed", [(16, 1), (32, 2), (32, 3), (48, 4)])
+def test_tile_list_outgrowing_its_capacity_is_rebuilt(side, seed):
+    """Few 16x16 tiles (list capacity 2 per tile) and a front that keeps leaving and re-entering
+    tiles: one iteration per host call, so the periodic list rebuild of the long graphs never
+    runs and appended entries pile up until k_update rebuilds the list itself."""
+    rng = np.random.default_rng(seed)
+    img = crim_synth.xray_like(side, side, 7100 + seed, colour=True)
+    m = np.zeros((side, side), np.uint8)
+    # thin diagonal and straight strokes crossing the tile borders, plus salt
+    for k in range(2, side - 2):
+        m[k, k] = 1
+        m[k, side - 1 - k] = 1
+    m[side // 2, 2:side - 2] = 1
+    m[rng.random((side, side)) < 0.06] = 1
+    m[:2, :] = 0
+    m[-2:, :] = 0
+    m[:, :2] = 0
+    m[:, -2:] = 0
+    oout, oconf, _, otr, n = c_oracle.run(img, m, 3)
+    with capi.Engine(side, side, 3) as eng:
+        eng.upload(img, m)
+        rem = 1
+        while rem:
+            _, rem = eng.run(max_iters=1)
+        st = _debug_state(eng)
+        out, conf, _ = eng.download(want_conf=True)
+        tr = eng.trace(0)
+    assert np.array_equal(tr, otr.astype(capi.ITER_REC_DTYPE))
+    assert np.array_equal(out[0], oout) and np.array_equal(conf[0], oconf)
+    ntiles = ((side + 15) // 16) ** 2
+    assert st[4] <= 2 * ntiles              # tcount stays within the list
+    if side <= 32:
+        assert st[10] > 0, "the in-kernel rebuild never ran: the case does not cover it"
+
+
 def test_batch_of_different_masks():
     H, W, B = 64, 64, 5
     imgs = np.stack([crim_synth.xray_like(H, W, 700 + i, colour=(i % 2 == 0)) for i in range(B)])
