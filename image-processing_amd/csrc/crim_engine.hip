@@ -985,6 +985,27 @@ extern "C" int crim_debug_state(crim_t* h, int index, int* out16) {
     return CRIM_OK;
 }
 
+// Diagnostic: pads image `index`'s tile list to its capacity with copies of its first entry (as
+// stale duplicates would), so that the next appended tile finds the list full.  Not part of the
+// public header.
+extern "C" int crim_debug_fill_tile_list(crim_t* h, int index) {
+    if (!h) return fail(CRIM_ERR_ARG, "crim_debug_fill_tile_list: null handle");
+    const Params& p = h->prm;
+    if (index < 0 || index >= p.B) return fail(CRIM_ERR_ARG, "crim_debug_fill_tile_list: index %d of %d", index, p.B);
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    ImgState st;
+    HIP_TRY(hipMemcpy(&st, p.st + index, sizeof(st), hipMemcpyDeviceToHost));
+    std::vector<int> tl((size_t)p.tcap);
+    HIP_TRY(hipMemcpy(tl.data(), p.tlist + (size_t)index * p.tcap, tl.size() * sizeof(int), hipMemcpyDeviceToHost));
+    if (st.tcount == 0 || st.tcount > (unsigned)p.tcap) return fail(CRIM_ERR_STATE, "crim_debug_fill_tile_list: list holds %u entries", st.tcount);
+    for (int i = (int)st.tcount; i < p.tcap; ++i) tl[i] = tl[0];
+    st.tcount = (unsigned)p.tcap;
+    HIP_TRY(hipMemcpy(p.tlist + (size_t)index * p.tcap, tl.data(), tl.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(p.st + index, &st, sizeof(st), hipMemcpyHostToDevice));
+    return CRIM_OK;
+}
+
 extern "C" int crim_peek_fields(crim_t* h, int index, uint8_t* front_out, double* data_out,
                                 double* priority_out) {
     if (!h) return fail(CRIM_ERR_ARG, "crim_peek_fields: null handle");

@@ -310,39 +310,35 @@ def _debug_state(eng, index=0):
     return list(buf)
 
 
-@pytest.mark.parametrize("side,seed", [(16, 1), (32, 2), (32, 3), (48, 4)])
-def test_tile_list_outgrowing_its_capacity_is_rebuilt(side, seed):
-    """Few 16x16 tiles (list capacity 2 per tile) and a front that keeps leaving and re-entering
-    tiles: one iteration per host call, so the periodic list rebuild of the long graphs never
-    runs and appended entries pile up until k_update rebuilds the list itself."""
-    rng = np.random.default_rng(seed)
-    img = crim_synth.xray_like(side, side, 7100 + seed, colour=True)
-    m = np.zeros((side, side), np.uint8)
-    # thin diagonal and straight strokes crossing the tile borders, plus salt
-    for k in range(2, side - 2):
-        m[k, k] = 1
-        m[k, side - 1 - k] = 1
-    m[side // 2, 2:side - 2] = 1
-    m[rng.random((side, side)) < 0.06] = 1
-    m[:2, :] = 0
-    m[-2:, :] = 0
-    m[:, :2] = 0
-    m[:, -2:] = 0
-    oout, oconf, _, otr, n = c_oracle.run(img, m, 3)
-    with capi.Engine(side, side, 3) as eng:
+@pytest.mark.parametrize("stepwise", [True, False])
+def test_tile_list_outgrowing_its_capacity_is_rebuilt(stepwise):
+    """A hole that covers whole 16x16 tiles: their front counts leave zero only when the fill
+    reaches them, which appends them to the tile list.  The list is padded to its capacity with
+    stale duplicates first, so the first such append finds it full and k_update must rebuild it
+    from the counts (one iteration per host call: the periodic rebuild of the long graphs never
+    runs) -- every later target must still be the oracle's."""
+    H, W, p = 80, 96, 9
+    img = crim_synth.xray_like(H, W, 7100, colour=True)
+    m = np.zeros((H, W), np.uint8)
+    m[12:70, 14:84] = 1
+    oout, oconf, _, otr, n = c_oracle.run(img, m, p)
+    with capi.Engine(H, W, p) as eng:
         eng.upload(img, m)
-        rem = 1
-        while rem:
-            _, rem = eng.run(max_iters=1)
+        assert capi.load_library().crim_debug_fill_tile_list(eng._h, 0) == 0
+        if stepwise:
+            rem = 1
+            while rem:
+                _, rem = eng.run(max_iters=1)
+        else:
+            eng.run()
         st = _debug_state(eng)
         out, conf, _ = eng.download(want_conf=True)
         tr = eng.trace(0)
     assert np.array_equal(tr, otr.astype(capi.ITER_REC_DTYPE))
     assert np.array_equal(out[0], oout) and np.array_equal(conf[0], oconf)
-    ntiles = ((side + 15) // 16) ** 2
+    ntiles = ((H + 15) // 16) * ((W + 15) // 16)
     assert st[4] <= 2 * ntiles              # tcount stays within the list
-    if side <= 32:
-        assert st[10] > 0, "the in-kernel rebuild never ran: the case does not cover it"
+    assert st[10] > 0, "the in-kernel rebuild never ran"
 
 
 def test_batch_of_different_masks():
