@@ -94,6 +94,8 @@ def load_library():
     lib.crim_profile.restype = ci
     lib.crim_profile.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(cl),
                                  ctypes.POINTER(ctypes.c_double)]
+    lib.crim_inpaint_noalloc.restype = ci
+    lib.crim_inpaint_noalloc.argtypes = [ci, ci, ci, ci, vp, vp, vp, ctypes.POINTER(cl)]
     lib.crim_peek_fields.restype = ci
     lib.crim_peek_fields.argtypes = [vp, ci, vp, vp, vp]
     _lib = lib
@@ -124,6 +126,19 @@ def lab_tables():
     k = np.zeros(9, np.int32)
     _check(load_library().crim_lab_tables(g.ctypes.data, c.ctypes.data, k.ctypes.data))
     return g, c, k
+
+
+NOALLOC_MAX_PIXELS = 512 * 512
+
+
+def inpaint_noalloc(height, width, patch_size, d_bgr_ptr, d_mask_ptr, d_out_ptr, device=0):
+    """One image, device buffers in and out, no allocation inside the library (state lives in a
+    static device array; H*W <= NOALLOC_MAX_PIXELS).  Returns the iteration count."""
+    it = ctypes.c_long()
+    _check(load_library().crim_inpaint_noalloc(
+        int(height), int(width), int(patch_size), int(device), ctypes.c_void_p(int(d_bgr_ptr)),
+        ctypes.c_void_p(int(d_mask_ptr)), ctypes.c_void_p(int(d_out_ptr)), ctypes.byref(it)))
+    return it.value
 
 
 class Engine:

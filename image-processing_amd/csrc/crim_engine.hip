@@ -1026,3 +1026,158 @@ extern "C" int crim_peek_fields(crim_t* h, int index, uint8_t* front_out, double
     if (priority_out) HIP_TRY(hipMemcpy(priority_out, d_prio, HW * sizeof(double), hipMemcpyDeviceToHost));
     return CRIM_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// One-call inpaint that allocates nothing
+// ------------------------------------------------------------------------------------------
+// For callers that cannot allocate device memory (tight serving loops, harnesses that forbid it):
+// the whole engine state of ONE image -- working image, search planes, mask, grey, gradient,
+// confidence ping-pong, window validity, tile lists, loop state, target descriptor, the per-wave
+// and per-block partial results of the priority and search stages, Lab tables -- lives in a
+// file-scope device array instead of hipMalloc'ed buffers.  Every GPU holds its own copy of the
+// array (at its own address) until the process ends.  The array keeps the last call's contents:
+// whatever must start from a known value is cleared or rewritten at the top of each call.
+
+#define CRIM_NOALLOC_BYTES ((size_t)44 * CRIM_NOALLOC_MAX_PIXELS + ((size_t)1 << 18))
+static __device__ __align__(256) unsigned char scratch[CRIM_NOALLOC_BYTES];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex[kMaxDevices];       // calls on one GPU share that GPU's array: one at a time
+unsigned char* g_scratch_ptr[kMaxDevices];     // device address of `scratch` on each GPU
+
+// Address of this GPU's copy of `scratch` (looked up once per device, with that device current).
+// Host code never uses the array's name for anything else: the name is a host-side stand-in, not
+// a device address.
+int scratch_base(int device, unsigned char** out) {
+    if (!g_scratch_ptr[device]) {
+        void* ptr = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr)
+            return fail(CRIM_ERR_HIP, "crim_inpaint_noalloc: hipGetSymbolAddress(scratch) on device %d: %s",
+                        device, hipGetErrorString(e));
+        g_scratch_ptr[device] = (unsigned char*)ptr;
+    }
+    *out = g_scratch_ptr[device];
+    return CRIM_OK;
+}
+
+// Hands out 256-byte aligned pieces of the array.
+struct Carver {
+    unsigned char* base;
+    size_t used = 0;
+    template <typename T>
+    void take(T** ptr, size_t bytes) {
+        *ptr = (T*)(base + used);
+        used += (bytes + 255) & ~(size_t)255;
+    }
+};
+}  // namespace
+
+extern "C" int crim_inpaint_noalloc(int H, int W, int patch_size, int device, const void* d_bgr,
+                                    const void* d_mask, void* d_bgr_out, long* iters_done) {
+    if (!d_bgr || !d_mask || !d_bgr_out) return fail(CRIM_ERR_ARG, "crim_inpaint_noalloc: null argument");
+    if (H < 1 || W < 1) return fail(CRIM_ERR_ARG, "crim_inpaint_noalloc: bad shape %d x %d", H, W);
+    if (patch_size < 1 || patch_size > CRIM_MAX_PATCH)
+        return fail(CRIM_ERR_ARG, "crim_inpaint_noalloc: patch_size %d outside 1..%d", patch_size, CRIM_MAX_PATCH);
+    if ((long)H * W > (long)CRIM_NOALLOC_MAX_PIXELS)
+        return fail(CRIM_ERR_ARG, "crim_inpaint_noalloc: %d x %d = %ld pixels exceed the limit of %d "
+                    "(use crim_create / crim_run for larger images)", H, W, (long)H * W, CRIM_NOALLOC_MAX_PIXELS);
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev || device >= kMaxDevices)
+        return fail(CRIM_ERR_ARG, "crim_inpaint_noalloc: device %d of %d", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    std::lock_guard<std::mutex> lock(g_scratch_mutex[device]);
+    unsigned char* base = nullptr;
+    {
+        const int rc = scratch_base(device, &base);
+        if (rc) return rc;
+    }
+    Params p;
+    init_geometry(p, 1, H, W, patch_size, 0);
+    const size_t HW = (size_t)H * W;
+    const LabTables& t = lab_tables();
+    memcpy(p.coef, t.coef, sizeof(p.coef));
+    const size_t planes_bytes = (size_t)CRIM_NPL * H * p.Wp + (size_t)64 * p.Wp;
+    const size_t invalid_bytes = (size_t)H * p.Wi;
+    const size_t invbits_bytes = (size_t)H * p.Wb * sizeof(unsigned long long);
+    uint16_t *d_gamma = nullptr, *d_cbrt = nullptr;
+    Carver c{base};
+    c.take(&p.bgr, HW * 3);
+    c.take(&p.planes, planes_bytes);
+    c.take(&p.mask, HW);
+    c.take(&p.grey, HW);
+    c.take(&p.grad, HW * sizeof(int));
+    c.take(&p.conf, 2 * HW * sizeof(double));
+    c.take(&p.invalid, invalid_bytes);
+    c.take(&p.invbits, invbits_bytes);
+    c.take(&p.tfront, (size_t)p.tnx * p.tny * sizeof(int));
+    c.take(&p.tlist, (size_t)p.tcap * sizeof(int));
+    c.take(&p.st, sizeof(ImgState));
+    c.take(&p.desc, sizeof(Desc));
+    c.take(&p.plist, (size_t)p.pgrid * sizeof(PEntry));
+    c.take(&p.slist, (size_t)p.snx * p.sny * sizeof(SEntry));
+    c.take(&p.dbg, 64 * sizeof(long long));
+    c.take(&p.xchg, 64 * sizeof(SEntry));
+    c.take(&d_gamma, sizeof(t.gamma));
+    c.take(&d_cbrt, sizeof(t.cbrt_));
+    if (c.used > CRIM_NOALLOC_BYTES)
+        return fail(CRIM_ERR_ARG, "crim_inpaint_noalloc: a %d x %d image needs %zu bytes of state, the static "
+                    "buffer holds %zu (rows narrower than 32 pixels are padded heavily; use crim_create / crim_run)",
+                    H, W, c.used, (size_t)CRIM_NOALLOC_BYTES);
+    p.gamma_tab = d_gamma;
+    p.cbrt_tab = d_cbrt;
+    p.trace = nullptr;       // no per-iteration records
+    const hipStream_t s = nullptr;   // the default stream: creating one would allocate
+    // what the kernels expect to find zeroed / preset (the array still holds the previous call's state)
+    HIP_TRY(hipMemsetAsync(p.planes, 0, planes_bytes, s));
+    HIP_TRY(hipMemsetAsync(p.invalid, 1, invalid_bytes, s));
+    HIP_TRY(hipMemsetAsync(p.invbits, 0xff, invbits_bytes, s));
+    HIP_TRY(hipMemsetAsync(p.st, 0, sizeof(ImgState), s));
+    HIP_TRY(hipMemsetAsync(p.desc, 0, sizeof(Desc), s));
+    HIP_TRY(hipMemsetAsync(p.tfront, 0, (size_t)p.tnx * p.tny * sizeof(int), s));
+    HIP_TRY(hipMemsetAsync(p.tlist, 0, (size_t)p.tcap * sizeof(int), s));
+    HIP_TRY(hipMemcpyAsync(d_gamma, t.gamma, sizeof(t.gamma), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_cbrt, t.cbrt_, sizeof(t.cbrt_), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(p.bgr, d_bgr, HW * 3, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(p.mask, d_mask, HW, hipMemcpyDeviceToDevice, s));
+    launch_init(p, s, 0, 1);
+    HIP_TRY(hipGetLastError());
+    ImgState st;
+    HIP_TRY(hipMemcpyAsync(&st, p.st, sizeof(st), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    p.chroma = st.chroma ? 1 : 0;
+    // The loop of crim_run for one image, launched eagerly in rounds: a round is the number of
+    // iterations the image certainly still needs (each fills at most P*P pixels), or the need
+    // extrapolated from the last round's fill rate; iterations past the end are no-ops.
+    long done = 0, last = 0;
+    int prev_remaining = -1;
+    int rc = CRIM_OK;
+    for (;;) {
+        if (st.stalled) { rc = CRIM_ERR_NO_PROGRESS; break; }
+        if (!st.live) break;
+        long need = std::max(1L, ((long)st.remaining + p.P * p.P - 1) / (p.P * p.P));
+        const int filled = prev_remaining - st.remaining;
+        if (last > 0 && prev_remaining >= 0 && filled > 0)
+            need = std::max(need, (long)((double)st.remaining * (double)last / (double)filled));
+        need = std::min(need, 4096L);
+        prev_remaining = st.remaining;
+        for (long i = 0; i < need; ++i) {
+            if ((done + i) > 0 && (done + i) % COMPACT_PERIOD == 0) launch_compact(p, s);
+            launch_iteration(p, s);
+        }
+        done += need;
+        last = need;
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(&st, p.st, sizeof(st), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    HIP_TRY(hipMemcpyAsync(d_bgr_out, p.bgr, HW * 3, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (iters_done) *iters_done = st.iter;
+    if (rc == CRIM_ERR_NO_PROGRESS)
+        return fail(rc, "crim_inpaint_noalloc: an iteration filled no pixel while %d remain "
+                    "(the reference loop would not terminate)", st.remaining);
+    return CRIM_OK;
+}

@@ -118,6 +118,22 @@ int crim_download_batch(crim_t* h, int first, int count, uint8_t* bgr_out, doubl
 /* Dense device-side copy of the working images ([count][H][W][3]). */
 int crim_download_device(crim_t* h, int first, int count, void* d_bgr_out);
 
+/* The whole of crim_create + crim_upload_device + crim_run + crim_download_device + crim_destroy
+ * for ONE image, without allocating anything.  No counterpart in the reference; it is for callers
+ * that cannot allocate device memory while they run (tight serving loops, harnesses that forbid
+ * hipMalloc): all engine state, including the partial results of the priority and search stages,
+ * lives in one static device array of 44 * CRIM_NOALLOC_MAX_PIXELS + 256 KiB bytes (11.3 MiB)
+ * that each GPU the library runs on holds until the process ends.  d_bgr ([H][W][3]), d_mask
+ * ([H][W], nonzero = fill) and d_bgr_out ([H][W][3]) are dense device buffers on GPU `device`.
+ * H * W must not exceed CRIM_NOALLOC_MAX_PIXELS (every such shape with W >= 32 fits; narrower
+ * images may be refused because their plane rows are padded): CRIM_ERR_ARG otherwise.  Work is
+ * issued on the default stream and the call returns when the result is in d_bgr_out.  Calls for
+ * one GPU share that GPU's array: the library serialises them within a process (a lock per GPU);
+ * calls from different handles of crim_create are independent of it.  No per-iteration records. */
+#define CRIM_NOALLOC_MAX_PIXELS (512 * 512)
+int crim_inpaint_noalloc(int H, int W, int patch_size, int device, const void* d_bgr,
+                         const void* d_mask, void* d_bgr_out, long* iters_done);
+
 /* Per-iteration decisions of image `index` (parity instrument; no counterpart in the reference
  * beyond the values its loop computes at :62-74). */
 int crim_trace(crim_t* h, int index, crim_iter_rec* buf, long cap, long* n);

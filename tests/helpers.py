@@ -42,3 +42,47 @@ def golden_cases():
 def load_golden(name):
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     return {k: z[k] for k in z.files}
+
+
+class HipBuffers:
+    """Plain device allocations for tests, through the HIP runtime the engine library itself is
+    linked against (ctypes; no PyTorch, whose bundled runtime cannot initialise a GPU that the
+    system runtime already drives in the same process)."""
+
+    def __init__(self):
+        import ctypes
+        self._ct = ctypes
+        self._hip = ctypes.CDLL("libamdhip64.so.7")
+        self._hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+        self._hip.hipFree.argtypes = [ctypes.c_void_p]
+        self._hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        self._hip.hipMemset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]
+        self._live = []
+
+    def alloc(self, nbytes):
+        ptr = self._ct.c_void_p()
+        rc = self._hip.hipMalloc(self._ct.byref(ptr), max(int(nbytes), 1))
+        assert rc == 0 and ptr.value, "hipMalloc failed (%d)" % rc
+        self._live.append(ptr.value)
+        return ptr.value
+
+    def to_device(self, array):
+        a = np.ascontiguousarray(array)
+        ptr = self.alloc(a.nbytes)
+        assert self._hip.hipMemcpy(ptr, a.ctypes.data, a.nbytes, 1) == 0     # host to device
+        return ptr
+
+    def zeros(self, nbytes):
+        ptr = self.alloc(nbytes)
+        assert self._hip.hipMemset(ptr, 0, int(nbytes)) == 0
+        return ptr
+
+    def to_host(self, ptr, shape, dtype=np.uint8):
+        out = np.empty(shape, dtype)
+        assert self._hip.hipMemcpy(out.ctypes.data, ptr, out.nbytes, 2) == 0  # device to host
+        return out
+
+    def free_all(self):
+        for ptr in self._live:
+            self._hip.hipFree(ptr)
+        self._live = []
