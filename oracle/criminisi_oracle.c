@@ -78,6 +78,80 @@ static void bgr2lab(const uint8_t *bgr, uint8_t *lab, long npix, const uint16_t 
     }
 }
 
+/* _find_source_patch (:220-265) on a Lab frame: first arg-min, row-major, of
+ * float64(S) + distance over the windows free of masked pixels; (0,0) with cost +inf when there
+ * is none.  sat is scratch for (H+1)*(W+1) ints. */
+static void search(const uint8_t *lab, const uint8_t *msk, int32_t *sat, int H, int W, int r0,
+                   int r1, int c0, int c1, int *sy_out, int *sx_out, double *cost_out) {
+    const int ph = r1 - r0 + 1, pw = c1 - c0 + 1;
+    /* integral image of the mask for the window test (:250-255) */
+    const int SW = W + 1;
+    for (int x = 0; x <= W; x++) sat[x] = 0;
+    for (int y = 0; y < H; y++) {
+        int run = 0;
+        sat[(y + 1) * SW] = 0;
+        for (int x = 0; x < W; x++) {
+            run += msk[y * W + x];
+            sat[(y + 1) * SW + x + 1] = sat[y * SW + x + 1] + run;
+        }
+    }
+    long tconst = 0;
+    for (int i = 0; i < ph; i++)
+        for (int j = 0; j < pw; j++)
+            if (!msk[(r0 + i) * W + c0 + j])
+                for (int ch = 0; ch < 3; ch++) {
+                    long t = lab[((r0 + i) * W + c0 + j) * 3 + ch];
+                    tconst += t * t;
+                }
+    const double ty = (r0 + r1) / 2.0, tx = (c0 + c1) / 2.0;
+    double best_c = INFINITY;
+    int sy = 0, sx = 0;
+    for (int y = 0; y <= H - ph; y++)
+        for (int x = 0; x <= W - pw; x++) {
+            int msum = sat[(y + ph) * SW + x + pw] - sat[y * SW + x + pw] -
+                       sat[(y + ph) * SW + x] + sat[y * SW + x];
+            if (msum > 0) continue;
+            long s = 0;
+            for (int i = 0; i < ph; i++) {
+                const uint8_t *lrow = lab + ((long)(y + i) * W + x) * 3;
+                const uint8_t *trow = lab + ((long)(r0 + i) * W + c0) * 3;
+                const uint8_t *mrow = msk + (long)(r0 + i) * W + c0;
+                for (int j = 0; j < pw; j++) {
+                    if (mrow[j]) continue;
+                    int d0 = lrow[3 * j] - trow[3 * j];
+                    int d1 = lrow[3 * j + 1] - trow[3 * j + 1];
+                    int d2 = lrow[3 * j + 2] - trow[3 * j + 2];
+                    s += d0 * d0 + d1 * d1 + d2 * d2;
+                }
+            }
+            double dyy = ((double)y + ph / 2.0) - ty, dxx = ((double)x + pw / 2.0) - tx;
+            double cost = (double)(s - tconst) + sqrt(dyy * dyy + dxx * dxx);
+            if (cost < best_c) { best_c = cost; sy = y; sx = x; }
+        }
+    *sy_out = sy; *sx_out = sx; *cost_out = best_c;
+}
+
+/* The search alone, for a given image, mask and target pixel (used to check sampled iterations
+ * of runs too long to repeat on the CPU).  Returns 0, or -1 on allocation failure. */
+int crim_oracle_search(const uint8_t *image_bgr, const uint8_t *mask, int H, int W, int p, int tr,
+                       int tc, const uint16_t *gamma_tab, const uint16_t *cbrt_tab,
+                       const int32_t *coeffs, int32_t *sy, int32_t *sx, double *cost) {
+    const long np_ = (long)H * W;
+    const int half = (p - 1) / 2;
+    uint8_t *lab = malloc(np_ * 3), *msk = malloc(np_);
+    int32_t *sat = malloc((np_ + H + W + 1) * sizeof(int32_t));
+    if (!lab || !msk || !sat) { free(lab); free(msk); free(sat); return -1; }
+    for (long i = 0; i < np_; i++) msk[i] = mask[i] ? 1 : 0;
+    bgr2lab(image_bgr, lab, np_, gamma_tab, cbrt_tab, coeffs);
+    int r0 = tr - half < 0 ? 0 : tr - half, r1 = tr + half > H - 1 ? H - 1 : tr + half;
+    int c0 = tc - half < 0 ? 0 : tc - half, c1 = tc + half > W - 1 ? W - 1 : tc + half;
+    int y, x;
+    search(lab, msk, sat, H, W, r0, r1, c0, c1, &y, &x, cost);
+    *sy = y; *sx = x;
+    free(lab); free(msk); free(sat);
+    return 0;
+}
+
 /*
  * Runs the loop until the mask is empty or max_iters iterations were done (max_iters <= 0: no
  * limit).  image/mask are not modified.  Returns the number of iterations executed, or -1 on
@@ -189,50 +263,9 @@ long crim_oracle_run(const uint8_t *image_bgr, const uint8_t *mask_in, int H, in
         int c0 = tc - half < 0 ? 0 : tc - half, c1 = tc + half > W - 1 ? W - 1 : tc + half;
         int ph = r1 - r0 + 1, pw = c1 - c0 + 1;
         bgr2lab(img, lab, np_, gamma_tab, cbrt_tab, coeffs);
-        /* integral image of the mask for the window test (:250-255) */
-        const int SW = W + 1;
-        for (int x = 0; x <= W; x++) sat[x] = 0;
-        for (int y = 0; y < H; y++) {
-            int run = 0;
-            sat[(y + 1) * SW] = 0;
-            for (int x = 0; x < W; x++) {
-                run += msk[y * W + x];
-                sat[(y + 1) * SW + x + 1] = sat[y * SW + x + 1] + run;
-            }
-        }
-        long tconst = 0;
-        for (int i = 0; i < ph; i++)
-            for (int j = 0; j < pw; j++)
-                if (!msk[(r0 + i) * W + c0 + j])
-                    for (int ch = 0; ch < 3; ch++) {
-                        long t = lab[((r0 + i) * W + c0 + j) * 3 + ch];
-                        tconst += t * t;
-                    }
-        const double ty = (r0 + r1) / 2.0, tx = (c0 + c1) / 2.0;
-        double best_c = INFINITY;
-        int sy = 0, sx = 0;
-        for (int y = 0; y <= H - ph; y++)
-            for (int x = 0; x <= W - pw; x++) {
-                int msum = sat[(y + ph) * SW + x + pw] - sat[y * SW + x + pw] -
-                           sat[(y + ph) * SW + x] + sat[y * SW + x];
-                if (msum > 0) continue;
-                long s = 0;
-                for (int i = 0; i < ph; i++) {
-                    const uint8_t *lrow = lab + ((long)(y + i) * W + x) * 3;
-                    const uint8_t *trow = lab + ((long)(r0 + i) * W + c0) * 3;
-                    const uint8_t *mrow = msk + (long)(r0 + i) * W + c0;
-                    for (int j = 0; j < pw; j++) {
-                        if (mrow[j]) continue;
-                        int d0 = lrow[3 * j] - trow[3 * j];
-                        int d1 = lrow[3 * j + 1] - trow[3 * j + 1];
-                        int d2 = lrow[3 * j + 2] - trow[3 * j + 2];
-                        s += d0 * d0 + d1 * d1 + d2 * d2;
-                    }
-                }
-                double dyy = ((double)y + ph / 2.0) - ty, dxx = ((double)x + pw / 2.0) - tx;
-                double cost = (double)(s - tconst) + sqrt(dyy * dyy + dxx * dxx);
-                if (cost < best_c) { best_c = cost; sy = y; sx = x; }
-            }
+        double best_c;
+        int sy, sx;
+        search(lab, msk, sat, H, W, r0, r1, c0, c1, &sy, &sx, &best_c);
         /* ---- update (:267-308): the reference builds the whole new patch before writing it,
          * so source pixels are read before any target pixel changes ---- */
         double pconf = conf[tr * W + tc];

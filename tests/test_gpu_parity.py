@@ -515,6 +515,110 @@ def test_2048_prefix(p, iters):
     assert np.array_equal(out[0], oout) and np.array_equal(conf[0], oconf) and np.array_equal(msk[0], omask)
 
 
+def check_full_run_properties(img, mask, p, out, conf, msk, tr, rem, it):
+    """Size-independent properties of a completed fill (criminisi_inpainter.py:51-83, :267-308):
+    the mask is empty, known pixels are untouched, every iteration fills something, every source
+    window lies inside the image, confidences of filled pixels are in (0, 1], and the output is
+    exactly the input with the trace's patch copies applied in order."""
+    H, W = mask.shape
+    assert rem == 0 and not msk.any() and len(tr) == it
+    assert np.array_equal(out[mask == 0], img[mask == 0])
+    assert np.all(np.diff(tr["remaining"]) < 0) and tr["remaining"][-1] == 0
+    assert np.all(conf[mask == 1] > 0) and np.all(conf[mask == 1] <= 1) and np.all(conf[mask == 0] <= 1)
+    assert tr["sy"].min() >= 0 and tr["sx"].min() >= 0
+    assert tr["sy"].max() <= H - p and tr["sx"].max() <= W - p
+    assert np.all(np.isfinite(tr["cost"]))
+    rimg, rmsk = c_oracle.replay(img, mask, p, tr, len(tr))
+    assert not rmsk.any() and np.array_equal(rimg, out)
+
+
+def check_sampled_searches(img, mask, p, tr, picks):
+    """The search of a few iterations deep inside a long run against the oracle's search on the
+    state rebuilt from the trace (image and mask after the first k iterations)."""
+    for k in picks:
+        simg, smsk = c_oracle.replay(img, mask, p, tr, k)
+        sy, sx, cost = c_oracle.search(simg, smsk, p, int(tr["tr"][k]), int(tr["tc"][k]))
+        assert (sy, sx) == (int(tr["sy"][k]), int(tr["sx"][k])), "iteration %d" % k
+        assert cost == tr["cost"][k], "iteration %d" % k
+
+
+@pytest.mark.parametrize("p", [9, 15])
+def test_2048_full_run_properties_and_sampled_searches(p):
+    """BASELINE configs[3] to completion (2048x2048x3, 1024x1024 hole, patch 9 and 15): the
+    size-independent properties, plus the oracle's search on three states deep inside the run."""
+    S = 2048
+    img = crim_synth.xray_like(S, S, 4000 + S, colour=True)
+    mask = crim_synth.square_hole_mask(S, S, S // 2)
+    with capi.Engine(S, S, p) as eng:
+        eng.upload(img, mask)
+        it, rem = eng.run()
+        out, conf, msk = eng.download(want_conf=True, want_mask=True)
+        tr = eng.trace(0)
+    check_full_run_properties(img, mask, p, out[0], conf[0], msk[0], tr, rem, it)
+    n = len(tr)
+    check_sampled_searches(img, mask, p, tr, [n // 3, (2 * n) // 3, n - 1] if p == 9 else [n // 2])
+
+
+def test_4096_prefix_split_and_sampled_search():
+    """BASELINE configs[4] shape (4096x4096x3, 2048x2048 hole, patch 9): the first two iterations
+    against the oracle, with the search as one launch and divided into 8 parts (128 rows of search
+    tiles: 16 per part, several row tiles per block inside a part); then 1500 iterations both ways
+    must agree record for record, and the oracle's search confirms the last of them."""
+    S, p = 4096, 9
+    img = crim_synth.xray_like(S, S, 4000 + S, colour=True)
+    mask = crim_synth.square_hole_mask(S, S, S // 2)
+    oout, oconf, omask, otr, n = c_oracle.run(img, mask, p, max_iters=2)
+    traces = []
+    for parts in (0, 8):
+        with capi.Engine(S, S, p) as eng:
+            eng.split_virtual(parts)
+            eng.upload(img, mask)
+            eng.run(max_iters=2)
+            out, conf, msk = eng.download(want_conf=True, want_mask=True)
+            assert np.array_equal(eng.trace(0), otr.astype(capi.ITER_REC_DTYPE)), parts
+            assert np.array_equal(out[0], oout) and np.array_equal(msk[0], omask), parts
+            assert np.array_equal(conf[0], oconf), parts
+            del out, conf, msk
+            eng.run(max_iters=1498)
+            traces.append(eng.trace(0).copy())
+    assert len(traces[0]) == 1500 and np.array_equal(traces[0], traces[1])
+    check_sampled_searches(img, mask, p, traces[0], [1499])
+
+
+def test_dataset_images_all_100():
+    """BASELINE configs[0]: the reference's 100 dataset images (256x256, decoded with Pillow), mask
+    built on the GPU by the recipe of src/utils.py:79-100 (no perspective stage: it needs OpenCV),
+    patch 9, as ONE lock-step batch -- output image, confidence map and per-iteration trace of
+    every image against the committed results of the C oracle."""
+    import json
+    import zlib
+    import crim_batch_driver as drv
+    from helpers import GOLDEN
+    src = os.path.join(GOLDEN, "xray_images")
+    with open(os.path.join(GOLDEN, "xray_dataset_expected.json")) as f:
+        want = json.load(f)
+    with open(os.path.join(src, "MANIFEST.json")) as f:
+        manifest = json.load(f)
+    names = sorted(want)
+    assert len(names) == 100
+    imgs = np.stack([drv.read_bgr(os.path.join(src, n)) for n in names])
+    for i, n in enumerate(names):
+        if zlib.crc32(imgs[i].tobytes()) != manifest[n]["crc32_bgr"]:
+            pytest.skip("this host's JPEG decoder yields other pixels than the one the fixtures were made with")
+    with capi.Engine(256, 256, 9, batch=100) as eng:
+        eng.upload_automask(imgs, dilation_size=4)
+        it, rem = eng.run()
+        out, conf, msk = eng.download(want_conf=True, want_mask=True)
+        traces = [eng.trace(i) for i in range(100)]
+    assert rem == 0 and not msk.any()
+    for i, n in enumerate(names):
+        w = want[n]
+        assert len(traces[i]) == w["iterations"], n
+        assert zlib.crc32(np.ascontiguousarray(traces[i]).tobytes()) == w["crc32_trace"], n
+        assert zlib.crc32(out[i].tobytes()) == w["crc32_out"], n
+        assert zlib.crc32(conf[i].tobytes()) == w["crc32_conf"], n
+
+
 def test_device_mask_recipe_and_inpaint_image():
     """The GPU mask builder against the NumPy restatement of src/utils.py:79-100, and the
     inpaint_image mirror end to end against the committed fixture of a reference dataset image."""

@@ -244,3 +244,47 @@ def test_c_oracle_reproduces_golden(name):
     assert np.array_equal(np.stack([tr["tr"], tr["tc"], tr["sy"], tr["sx"]], 1), g["trace"])
     assert np.array_equal(tr["cost"], g["cost"])
     assert np.array_equal(tr["remaining"], g["remaining"])
+
+
+def test_dataset_fixture_matches_the_oracle_and_the_decoder():
+    """tests/golden/xray_dataset_expected.json was made by the C oracle: one image is recomputed
+    here; the decoded pixels of all 100 files must be the ones the fixtures were made from."""
+    import json
+    import os
+    import zlib
+    import crim_batch_driver as drv
+    from helpers import GOLDEN, pipeline_mask
+    from oracle import c_oracle
+    src = os.path.join(GOLDEN, "xray_images")
+    with open(os.path.join(GOLDEN, "xray_dataset_expected.json")) as f:
+        want = json.load(f)
+    with open(os.path.join(src, "MANIFEST.json")) as f:
+        manifest = json.load(f)
+    assert sorted(want) == sorted(manifest) and len(want) == 100
+    for n in sorted(want):
+        bgr = drv.read_bgr(os.path.join(src, n))
+        assert bgr.shape == (256, 256, 3)
+        assert zlib.crc32(bgr.tobytes()) == manifest[n]["crc32_bgr"], n
+    n = "im037-healthy.jpg" if "im037-healthy.jpg" in want else sorted(want)[36]
+    bgr = drv.read_bgr(os.path.join(src, n))
+    m = pipeline_mask(bgr, dilation_size=4)
+    assert int(m.sum()) == want[n]["mask_pixels"]
+    out, conf, _, tr, it = c_oracle.run(bgr, m, 9)
+    assert it == want[n]["iterations"]
+    assert zlib.crc32(out.tobytes()) == want[n]["crc32_out"]
+    assert zlib.crc32(conf.tobytes()) == want[n]["crc32_conf"]
+    assert zlib.crc32(np.ascontiguousarray(tr).tobytes()) == want[n]["crc32_trace"]
+
+
+def test_search_alone_and_replay_agree_with_the_full_loop():
+    import crim_synth
+    from oracle import c_oracle
+    img = crim_synth.xray_like(48, 52, 77, colour=True)
+    m = crim_synth.blob_mask(48, 52, 77, fraction=0.08, margin=7)
+    out, conf, _, tr, n = c_oracle.run(img, m, 7)
+    for k in (0, n // 2, n - 1):
+        simg, smsk = c_oracle.replay(img, m, 7, tr, k)
+        sy, sx, cost = c_oracle.search(simg, smsk, 7, tr["tr"][k], tr["tc"][k])
+        assert (sy, sx, cost) == (tr["sy"][k], tr["sx"][k], tr["cost"][k])
+    rimg, rmsk = c_oracle.replay(img, m, 7, tr, n)
+    assert np.array_equal(rimg, out) and not rmsk.any()
