@@ -1,23 +1,29 @@
 #!/usr/bin/env python3
 """Benchmark of the Criminisi hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--configs 0,1,2,3,4]
 
-Workload (BASELINE.json configs[1]): 256x256 grey X-ray-like images replicated to 3 channels, a
-synthetic 10 % mask, patch_size 9.  One GPU fills a batch of B such images in lock step; a
-"step" is one complete pass of the fill loop over that batch (every image inpainted from its
-original mask to an empty mask), starting from inputs already resident in HBM.  With N > 1 every
-rank runs its own batch on its own GPU (weak scaling, no data-path collective).
+Headline workload (BASELINE.json configs[1]): 256x256 grey X-ray-like images replicated to 3
+channels, a synthetic 10 % mask, patch_size 9.  One GPU fills a batch of B such images in lock
+step; a "step" is one complete pass of the fill loop over that batch (every image inpainted from
+its original mask to an empty mask), starting from inputs already resident in HBM.  With N > 1
+every rank runs its own batch on its own GPU (weak scaling, no data-path collective).
 
-Prints ONE JSON line on rank 0: value = inpainted images / s over all GPUs; `evals_per_s_per_gpu`
-is the second half of the metric (masked patch-SSD window evaluations per second of search-kernel
-time on one GPU); `roofline` prices the dominant kernel (the search); `cpu_baseline` times the
-C oracle ("port") on the host cores over a bounded sample of the same images.
+Prints ONE JSON line on rank 0: value = inpainted images / s over all GPUs; `value_incl_host_io`
+= the same batch streamed from and to page-locked host memory (two half-batch engines on two
+host threads, so that one half's PCIe transfers run under the other half's kernels);
+`evals_per_s_per_gpu` is the second half of the metric (masked patch-SSD window evaluations per
+second of search-kernel time on one GPU); `roofline` prices the dominant kernel (the search);
+`cpu_baseline` times the C oracle ("port") on the host cores over a bounded sample of the same
+images; `configs` holds one entry per BASELINE.json config (the 100 dataset images, the headline,
+800 x 512^2, 2048^2 with patch 9 and 15 run to completion, 4096^2), each with its own throughput,
+iteration counts, evals/s and roofline of its search kernel.
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -36,28 +42,40 @@ MFMA_I8_PEAK_TOPS = 5033.2         # 256 CU x 4 SIMD x 1024 MAC/clk x 2 op x 2.4
 HBM_PEAK_GBS = 8000.0              # HBM3E
 
 
-COLOUR = False
-
-
-def _make_one(seed):
+def _make_one(args):
     import crim_synth
-    return (crim_synth.xray_like(H, W, seed, colour=COLOUR),
-            crim_synth.blob_mask(H, W, seed, fraction=MASK_FRACTION, margin=PATCH))
+    h, w, seed, colour = args
+    return (crim_synth.xray_like(h, w, seed, colour=colour),
+            crim_synth.blob_mask(h, w, seed, fraction=MASK_FRACTION, margin=PATCH))
 
 
-def make_batch(batch, rank):
+def host_cores():
+    """Cores this process may actually use: the affinity mask, further limited by OMP_NUM_THREADS
+    when the box sets it (a shared host shows every CPU of the machine in os.cpu_count())."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    env = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    if env > 0:
+        n = min(n, env)
+    return max(1, n)
+
+
+def make_batch(batch, h, w, config_id, first_index, colour):
     """Seeded synthetic images and masks (seed = 1000 * config + global image index), generated on
     a few host processes (forked before this process touches the GPU)."""
     import multiprocessing as mp
-    seeds = [1000 * CONFIG_ID + rank * batch + i for i in range(batch)]
-    imgs = np.empty((batch, H, W, 3), np.uint8)
-    masks = np.empty((batch, H, W), np.uint8)
-    workers = max(1, min(16, os.cpu_count() or 1, batch // 32))
+    tasks = [(h, w, 1000 * config_id + first_index + i, colour) for i in range(batch)]
+    imgs = np.empty((batch, h, w, 3), np.uint8)
+    masks = np.empty((batch, h, w), np.uint8)
+    workers = max(1, min(host_cores(), batch // 8))
     if workers > 1:
         with mp.get_context("fork").Pool(workers) as pool:
-            res = pool.map(_make_one, seeds, chunksize=16)
+            res = pool.map(_make_one, tasks, chunksize=max(1, min(16, batch // (4 * workers))))
     else:
-        res = [_make_one(s) for s in seeds]
+        res = [_make_one(t) for t in tasks]
     for i, (im, mk) in enumerate(res):
         imgs[i] = im
         masks[i] = mk
@@ -95,8 +113,7 @@ def cpu_baseline(imgs, masks, budget_images_per_core=4):
     import multiprocessing as mp
     from oracle import c_oracle
     c_oracle._lib()
-    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
-    cores = max(1, min(cores, os.cpu_count() or 1))
+    cores = host_cores()
     n = min(len(imgs), cores * budget_images_per_core)
     tasks = [(imgs[i], masks[i]) for i in range(n)]
     t0 = time.time()
@@ -106,9 +123,215 @@ def cpu_baseline(imgs, masks, budget_images_per_core=4):
     iters = sum(r[1] for r in res)
     return {"_crc": [r[2] for r in res],
             "value": n / wall, "unit": "images/s", "cores": cores, "kind": "port",
+            "host_cpus_visible": os.cpu_count(),
             "sample": "%d of the batch's 256x256 images (first by index), C oracle "
-                      "oracle/criminisi_oracle.c, one image per process, %d processes; "
-                      "%.1f s wall, %d iterations" % (n, cores, wall, iters)}
+                      "oracle/criminisi_oracle.c, one image per process, %d processes = every core this "
+                      "job may use (affinity mask and OMP_NUM_THREADS; os.cpu_count() shows %s for the "
+                      "whole machine); %.1f s wall, %d iterations" % (n, cores, os.cpu_count(), wall, iters)}
+
+
+def cpu_seconds_per_iteration(img, mask, patch, iters=2):
+    """The C oracle's first `iters` iterations on one large image (a full CPU run takes hours)."""
+    from oracle import c_oracle
+    t = time.time()
+    n = c_oracle.run(img, mask, patch, max_iters=iters, want_trace=False)[4]
+    return (time.time() - t) / max(n, 1)
+
+
+# --------------------------------------------------------------------------------------------
+# roofline helpers
+# --------------------------------------------------------------------------------------------
+
+def search_roofline(capi, h, w, patch, batch, upload, kernel, planes, hbm_resident, device, max_iters=0,
+                    traffic=None):
+    """One more pass (bounded by max_iters) on an engine that brackets every search launch with HIP
+    events on the engine's own stream, each bracketed launch alone on the GPU.  `planes` byte planes
+    plus the 1/8-byte validity bitmap are the algorithmic bytes per pixel, image and iteration."""
+    with capi.Engine(h, w, patch, batch=batch, device=device,
+                     flags=capi.FLAG_PROFILE_SOLO | capi.FLAG_NO_TRACE) as pe:
+        upload(pe)
+        pe.run(max_iters)
+        ms, launches, evals = pe.profile()
+    P = 2 * ((patch - 1) // 2) + 1
+    windows = (h - P + 1) * (w - P + 1)
+    bytes_per_window = (planes + 0.125) * h * w / windows
+    algo_bytes = evals * bytes_per_window
+    gbs = algo_bytes / (ms * 1e-3) / 1e9
+    tops = evals * P * P * 3 * 2 / (ms * 1e-3) / 1e12
+    r = {"kernel": kernel, "avg_launch_us": 1e3 * ms / max(launches, 1), "launches": launches,
+         "algorithmic_bytes_per_launch": algo_bytes / max(launches, 1),
+         "hbm_equiv_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
+         "mfma_achieved_tops": tops, "mfma_peak_tops": MFMA_I8_PEAK_TOPS, "mfma_frac": tops / MFMA_I8_PEAK_TOPS,
+         "traffic": traffic}
+    if hbm_resident:
+        r.update({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS})
+    else:
+        # the planes of these images stay in the 256 MB Infinity Cache between iterations: the matrix
+        # cores are the roof that applies (243 or 675 algorithmic MAC per window)
+        r.update({"bound": "mfma", "achieved": tops, "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s",
+                  "frac": tops / MFMA_I8_PEAK_TOPS})
+    return r, evals / (ms * 1e-3)
+
+
+# --------------------------------------------------------------------------------------------
+# per-config measurements (rank 0, single-GPU runs)
+# --------------------------------------------------------------------------------------------
+
+def config_dataset(capi, device, steps):
+    """configs[0]: the reference's 100 dataset images (scripts/main.py loop), patch 9, one lock-step
+    batch; host arrays in, host arrays out."""
+    import crim_batch_driver as drv
+    src = os.path.join(ROOT, "tests", "golden", "xray_images")
+    names = sorted(f for f in os.listdir(src) if f.endswith(".jpg"))
+    imgs = np.stack([drv.read_bgr(os.path.join(src, n)) for n in names])
+    B = len(names)
+    pin_in = capi.pinned_empty(imgs.shape)
+    pin_in[:] = imgs
+    imgs = pin_in
+    out = capi.pinned_empty(imgs.shape)
+    try:
+        with capi.Engine(256, 256, 9, batch=B, device=device, flags=capi.FLAG_NO_TRACE) as eng:
+            def step():
+                eng.upload_automask(imgs, dilation_size=4)
+                eng.run()
+                eng.download(out=out)
+            step()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            dt = (time.perf_counter() - t0) / steps
+            iters = np.array([eng.iterations(i) for i in range(B)])
+        roof, evals_s = search_roofline(capi, 256, 256, 9, B, lambda e: e.upload_automask(imgs, dilation_size=4),
+                                        "k_search_pipe<9, true>", 5, False, device)
+    finally:
+        capi.pinned_free(imgs)
+        capi.pinned_free(out)
+    return {"workload": "BASELINE configs[0]: the reference's %d dataset images (256x256, false colour, decoded "
+                        "with Pillow), mask built on the GPU by the recipe of src/utils.py:79-100 without the "
+                        "perspective stage (it needs OpenCV), patch_size 9, one lock-step batch; time covers host "
+                        "-> device, mask construction, the fill loop and device -> host (no JPEG coding)" % B,
+            "images": B, "images_per_s_incl_host_io": B / dt, "ms_per_batch": 1e3 * dt,
+            "iterations_per_image_mean": float(iters.mean()), "iterations_per_image_max": int(iters.max()),
+            "us_per_lockstep_iteration": 1e6 * dt / int(iters.max()),
+            "evals_per_s_per_gpu": evals_s, "roofline": roof}
+
+
+def config_512_batch(capi, torch, device, imgs, masks, steps):
+    """configs[2] on one GPU: 800 synthetic 512x512 false-colour images, 10 % masks, patch 9."""
+    B = len(imgs)
+    d_img = torch.from_numpy(imgs).cuda()
+    d_mask = torch.from_numpy(masks).cuda()
+    d_out = torch.empty_like(d_img)
+    torch.cuda.synchronize()
+    with capi.Engine(512, 512, 9, batch=B, device=device, flags=capi.FLAG_NO_TRACE) as eng:
+        def step():
+            eng.upload_device(d_img.data_ptr(), d_mask.data_ptr())
+            eng.run()
+            eng.download_device(d_out.data_ptr())
+        step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        iters = np.array([eng.iterations(i) for i in range(B)])
+    roof, evals_s = search_roofline(
+        capi, 512, 512, 9, B, lambda e: e.upload_device(d_img.data_ptr(), d_mask.data_ptr()),
+        "k_search_pipe<9, true>", 5, True, device, max_iters=200)
+    del d_img, d_mask, d_out
+    return {"workload": "BASELINE configs[2] on one GPU: %d synthetic 512x512 false-colour images, 10 %% masks, "
+                        "patch_size 9, one lock-step batch, inputs and outputs resident in HBM" % B,
+            "images": B, "images_per_s": B / dt, "ms_per_batch": 1e3 * dt,
+            "iterations_per_image_mean": float(iters.mean()), "iterations_per_image_max": int(iters.max()),
+            "evals_per_s_per_gpu": evals_s, "roofline": roof,
+            "roofline_note": "search launches of the first 200 lock-step iterations, each alone on the GPU"}
+
+
+def config_large(capi, device, side, patch, config_index, profile_iters=1500):
+    """configs[3] / configs[4]: one side x side false-colour image with a centred hole of a quarter
+    of the frame, run to completion."""
+    import crim_synth
+    img = crim_synth.xray_like(side, side, 4000 + side, colour=True)
+    mask = crim_synth.square_hole_mask(side, side, side // 2)
+    cpu_s = cpu_seconds_per_iteration(img, mask, patch)
+    with capi.Engine(side, side, patch, device=device, flags=capi.FLAG_NO_TRACE) as eng:
+        eng.upload(img, mask)
+        eng.run(max_iters=64)              # builds the graphs, warms the caches
+        eng.upload(img, mask)
+        t0 = time.perf_counter()
+        it, rem = eng.run()
+        dt = time.perf_counter() - t0
+        out = eng.download()[0][0]
+    ok = bool(rem == 0 and np.array_equal(out[mask == 0], img[mask == 0]))
+    P = 2 * ((patch - 1) // 2) + 1
+    windows = (side - P + 1) ** 2
+    roof, evals_s = search_roofline(capi, side, side, patch, 1, lambda e: e.upload(img, mask),
+                                    "k_search_pipe<%d, true>" % P, 5, False, device, max_iters=profile_iters)
+    return {"workload": "BASELINE configs[%d]: one %dx%d false-colour image, centred %dx%d hole (25 %%), "
+                        "patch_size %d, filled to completion" % (config_index, side, side, side // 2, side // 2, patch),
+            "iterations": int(it), "seconds": dt, "images_per_s": 1.0 / dt,
+            "us_per_iteration": 1e6 * dt / max(it, 1),
+            "evals_per_s_whole_iteration": windows * it / dt,
+            "evals_per_s_per_gpu": evals_s,
+            "search_share_of_iteration": roof["avg_launch_us"] / (1e6 * dt / max(it, 1)),
+            "completed_and_known_pixels_untouched": ok,
+            "cpu_port_s_per_iteration": cpu_s,
+            "cpu_port_note": "C oracle, first 2 iterations, one core; a full CPU run would take "
+                             "%.1f hours at that rate" % (cpu_s * it / 3600.0),
+            "roofline": roof,
+            "roofline_note": "search launches of the first %d iterations, each alone on the GPU" % profile_iters}
+
+
+# --------------------------------------------------------------------------------------------
+# host-I/O-inclusive throughput of the headline batch
+# --------------------------------------------------------------------------------------------
+
+def streamed_images_per_s(capi, device, imgs, masks, steps):
+    """The headline batch from and to page-locked host memory: two engines of half the batch on two
+    host threads, each looping upload -> fill -> download, so one half's transfers overlap the
+    other half's kernels."""
+    B = len(imgs)
+    half = B // 2
+    pin_img, pin_msk, out = (capi.pinned_empty(imgs.shape), capi.pinned_empty(masks.shape),
+                             capi.pinned_empty(imgs.shape))
+    pin_img[:] = imgs
+    pin_msk[:] = masks
+    imgs, masks = pin_img, pin_msk
+    engines = [capi.Engine(H, W, PATCH, batch=half, device=device, flags=capi.FLAG_NO_TRACE) for _ in range(2)]
+    errors = []
+
+    def loop(k, n):
+        lo = k * half
+        try:
+            for _ in range(n):
+                engines[k].upload(imgs[lo:lo + half], masks[lo:lo + half])
+                engines[k].run()
+                engines[k].download(out=out[lo:lo + half])
+        except Exception as e:            # noqa: BLE001 (reported to the main thread)
+            errors.append(e)
+
+    def timed(n):
+        ts = [threading.Thread(target=loop, args=(k, n)) for k in range(2)]
+        t0 = time.perf_counter()
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        return time.perf_counter() - t0
+
+    try:
+        timed(1)
+        dt = timed(steps)
+        if errors:
+            raise errors[0]
+    finally:
+        for e in engines:
+            e.close()
+    result = out[:64].copy()
+    for a in (imgs, masks, out):
+        capi.pinned_free(a)
+    return 2 * half * steps / dt, result
 
 
 def main():
@@ -117,21 +340,26 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=8192)
+    ap.add_argument("--configs", default="0,1,2,3,4",
+                    help="BASELINE.json configs to measure besides the headline (single-GPU runs; '' for none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-host-io", action="store_true")
     ap.add_argument("--colour", action="store_true",
                     help="false-colour images (5-plane search) instead of the grey ones of BASELINE configs[1]; "
                          "side measurement, run with --no-roofline")
     args = ap.parse_args()
-    global COLOUR
-    COLOUR = args.colour
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     distributed = world > 1
+    want = set(int(c) for c in args.configs.split(",") if c.strip() != "") if world == 1 else set()
     B = args.batch
-    imgs, masks = make_batch(B, rank)
+    imgs, masks = make_batch(B, H, W, CONFIG_ID, rank * B, args.colour)
+    imgs512 = masks512 = None
+    if 2 in want:
+        imgs512, masks512 = make_batch(800, 512, 512, 3, 0, True)
 
     # CPU baseline first (rank 0, single-GPU runs only), before this process touches the GPU:
     # the worker pool forks.
@@ -164,7 +392,7 @@ def main():
     d_out = torch.empty_like(d_img)
     torch.cuda.synchronize()
 
-    eng = capi.Engine(H, W, PATCH, batch=B, device=local_rank)
+    eng = capi.Engine(H, W, PATCH, batch=B, device=local_rank, flags=capi.FLAG_NO_TRACE)
 
     def step():
         eng.upload_device(d_img.data_ptr(), d_mask.data_ptr())
@@ -214,6 +442,8 @@ def main():
                    "iterations_per_image_mean": float(iters_per_image.mean()),
                    "iterations_per_image_max": int(iters_per_image.max())},
     }
+    gpu_first = eng.download(0, min(B, 64))[0] if cpu is not None else None
+    eng.close()
 
     if rank == 0 and not args.no_roofline:
         # Same batch once more on an engine that brackets every search launch with HIP events
@@ -223,57 +453,74 @@ def main():
         # launch there also waits for, or shares the CUs with, the other half's kernels; the
         # second pass below brackets the launches under those conditions (stream-ordered events:
         # the wait is included).
-        with capi.Engine(H, W, PATCH, batch=B, device=local_rank, flags=capi.FLAG_PROFILE_SOLO) as pe:
-            pe.upload_device(d_img.data_ptr(), d_mask.data_ptr())
-            pe.run()
-            ms, launches, evals = pe.profile()
-        with capi.Engine(H, W, PATCH, batch=B, device=local_rank, flags=capi.FLAG_PROFILE) as pe:
-            pe.upload_device(d_img.data_ptr(), d_mask.data_ptr())
+        def up(e):
+            e.upload_device(d_img.data_ptr(), d_mask.data_ptr())
+        roof, evals_s = search_roofline(capi, H, W, PATCH, B, up,
+                                        "k_search_pipe<9, %s>" % ("true" if args.colour else "false"),
+                                        5 if args.colour else 3, True, local_rank,
+                                        traffic=pmc_traffic_per_launch(B / 2.0 if B >= 32 else B))
+        with capi.Engine(H, W, PATCH, batch=B, device=local_rank, flags=capi.FLAG_PROFILE | capi.FLAG_NO_TRACE) as pe:
+            up(pe)
             pe.run()
             ov_ms, ov_launches, _ = pe.profile()
-        # Roofs for the search of a batch of grey images.  HBM: every iteration reads, per image,
-        # the three byte planes it scores (L-128 and the two digits of Q) and the window-validity
-        # bitmap once: 3 + 1/8 bytes per pixel, i.e. 3.125*H*W / ((H-8)*(W-8)) bytes per window
-        # scored; the working set (gigabytes) is far beyond L2 and the 256 MB Infinity Cache.
-        # MFMA: 243 algorithmic multiply-accumulates per window (960 issued, see the note).  The
-        # HBM roof is the nearer one (per launch of 2048 images: 52 us against 48 us of issued
-        # MFMA work, 24 us of algorithmic MFMA work), so it is the one reported.
-        bytes_per_window = 3.125 * H * W / ((H - PATCH + 1) * (W - PATCH + 1))
-        algo_bytes = evals * bytes_per_window
-        achieved = algo_bytes / (ms * 1e-3) / 1e9
-        ops = evals * PATCH * PATCH * 3 * 2
-        traffic = pmc_traffic_per_launch(B / 2.0 if B >= 32 else B)
-        result["evals_per_s_per_gpu"] = evals / (ms * 1e-3)
-        result["roofline"] = {
-            "bound": "hbm", "kernel": "k_search_pipe<9, false>",
-            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "avg_launch_us": 1e3 * ms / max(launches, 1), "launches": launches,
-            "algorithmic_bytes_per_launch": algo_bytes / max(launches, 1),
-            "overlapped_avg_launch_us": 1e3 * ov_ms / max(ov_launches, 1),
-            "mfma_achieved_tops": ops / (ms * 1e-3) / 1e12, "mfma_peak_tops": MFMA_I8_PEAK_TOPS,
-            "mfma_frac": ops / (ms * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS,
-            "note": "achieved/frac/avg_launch_us: every search launch of one pass over the batch, each "
-                    "alone on the GPU; overlapped_avg_launch_us: the same with the two halves of the "
-                    "batch on two streams as in the timed region (event to event, waiting for the other "
-                    "half's kernels included); "
-                    "algorithmic bytes = 3.125 B per pixel per image per iteration (3 byte planes + validity "
-                    "bitmap), one launch covers one lane = half the batch; traffic = HBM-side bytes per "
-                    "launch from the committed PMC passes (profiles/; FETCH_SIZE doubled for 16-byte "
-                    "loads, plus WRITE_SIZE): tiles overlap by 8 of 40 rows, every wave load is a whole KiB (10 % padding), and the blocks of one image "
-                    "share an XCD so that its L2 serves most of that overlap; mfma_*: integer ops (2 per MAC) against the dense i8 MFMA peak, 243 "
-                    "algorithmic MAC per window of 960 issued (each template row occupies 32 K-slots: 16 "
-                    "x shifts + 9 taps, padded; two rows per v_mfma_i32_16x16x64_i8)",
-        }
+        roof["overlapped_avg_launch_us"] = 1e3 * ov_ms / max(ov_launches, 1)
+        roof["note"] = ("achieved/frac/avg_launch_us: every search launch of one pass over the batch, each "
+                        "alone on the GPU; overlapped_avg_launch_us: the same with the two halves of the "
+                        "batch on two streams as in the timed region (event to event, waiting for the other "
+                        "half's kernels included); algorithmic bytes = 3.125 B per pixel per image per "
+                        "iteration (3 byte planes + validity bitmap), one launch covers one lane = half the "
+                        "batch; traffic = HBM-side bytes per launch from the committed PMC passes "
+                        "(profiles/; FETCH_SIZE doubled for 16-byte loads, plus WRITE_SIZE); mfma_*: integer "
+                        "ops (2 per MAC) against the dense i8 MFMA peak, 243 algorithmic MAC per window")
+        result["evals_per_s_per_gpu"] = evals_s
+        result["roofline"] = roof
+    del d_img, d_mask, d_out
+    torch.cuda.empty_cache()
+
+    if rank == 0 and world == 1 and not args.no_host_io:
+        v, streamed_out = streamed_images_per_s(capi, local_rank, imgs, masks, args.steps)
+        result["value_incl_host_io"] = v
+        result["host_io_note"] = ("same batch from and to page-locked host memory (H2D 262144 B + D2H 196608 B per "
+                                  "image over PCIe): two engines of %d images on two host threads, upload -> fill -> "
+                                  "download each, %d passes" % (B // 2, args.steps))
+        if gpu_first is not None:
+            result["host_io_outputs_identical"] = bool(np.array_equal(streamed_out[:len(gpu_first)], gpu_first))
+        del streamed_out
+
     if cpu is not None:
         # the sample's outputs double as a check of the timed run's results (outside the timed region)
         import zlib
         crcs = cpu.pop("_crc")
-        got, _, _ = eng.download(0, len(crcs))
-        same = sum(int(zlib.crc32(got[i].tobytes()) == c) for i, c in enumerate(crcs))
-        cpu["outputs_identical_to_gpu"] = "%d of %d" % (same, len(crcs))
+        same = sum(int(zlib.crc32(gpu_first[i].tobytes()) == c) for i, c in enumerate(crcs) if i < len(gpu_first))
+        cpu["outputs_identical_to_gpu"] = "%d of %d" % (same, min(len(crcs), len(gpu_first)))
         result["cpu_baseline"] = cpu
-    eng.close()
+
+    if rank == 0 and world == 1 and want:
+        del imgs, masks
+        cfgs = {}
+        if 0 in want:
+            cfgs["configs[0]"] = config_dataset(capi, local_rank, args.steps)
+        if 1 in want:
+            cfgs["configs[1]"] = {"workload": result["config"]["workload"], "images_per_s": value,
+                                  "images_per_s_incl_host_io": result.get("value_incl_host_io"),
+                                  "iterations_per_image_mean": float(iters_per_image.mean()),
+                                  "evals_per_s_per_gpu": result.get("evals_per_s_per_gpu"),
+                                  "roofline": {k: result["roofline"][k] for k in
+                                               ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_us")}
+                                  if "roofline" in result else None}
+        if 2 in want:
+            cfgs["configs[2]"] = config_512_batch(capi, torch, local_rank, imgs512, masks512, max(1, args.steps - 1))
+            del imgs512, masks512
+            torch.cuda.empty_cache()
+        if 3 in want:
+            cfgs["configs[3] patch 9"] = config_large(capi, local_rank, 2048, 9, 3)
+            cfgs["configs[3] patch 15"] = config_large(capi, local_rank, 2048, 15, 3)
+        if 4 in want:
+            cfgs["configs[4]"] = config_large(capi, local_rank, 4096, 9, 4)
+            cfgs["configs[4]"]["multi_gpu_note"] = ("one GPU; the intra-image split over N GPUs (RCCL all-gather of 16 B "
+                                                    "per rank per iteration) is measured by `bench.py --gpus N`")
+        result["configs"] = cfgs
+
     if rank == 0:
         print(json.dumps(result))
     if distributed:

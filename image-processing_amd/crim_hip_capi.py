@@ -94,6 +94,10 @@ def load_library():
     lib.crim_profile.restype = ci
     lib.crim_profile.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(cl),
                                  ctypes.POINTER(ctypes.c_double)]
+    lib.crim_host_alloc.restype = ci
+    lib.crim_host_alloc.argtypes = [ctypes.c_size_t, ctypes.POINTER(vp)]
+    lib.crim_host_free.restype = ci
+    lib.crim_host_free.argtypes = [vp]
     lib.crim_inpaint_noalloc.restype = ci
     lib.crim_inpaint_noalloc.argtypes = [ci, ci, ci, ci, vp, vp, vp, ctypes.POINTER(cl)]
     lib.crim_peek_fields.restype = ci
@@ -126,6 +130,22 @@ def lab_tables():
     k = np.zeros(9, np.int32)
     _check(load_library().crim_lab_tables(g.ctypes.data, c.ctypes.data, k.ctypes.data))
     return g, c, k
+
+
+def pinned_empty(shape, dtype=np.uint8):
+    """A NumPy array in page-locked host memory (uploads from / downloads into it are DMA
+    transfers that overlap with kernels).  Release it with pinned_free(array) once no view of it
+    is in use any more."""
+    dtype = np.dtype(dtype)
+    nbytes = int(np.prod(shape)) * dtype.itemsize
+    ptr = ctypes.c_void_p()
+    _check(load_library().crim_host_alloc(max(nbytes, 1), ctypes.byref(ptr)))
+    buf = (ctypes.c_uint8 * max(nbytes, 1)).from_address(ptr.value)
+    return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+
+def pinned_free(array):
+    _check(load_library().crim_host_free(ctypes.c_void_p(array.ctypes.data)))
 
 
 NOALLOC_MAX_PIXELS = 512 * 512
@@ -231,9 +251,13 @@ class Engine:
         return it.value, rem.value
 
     # -- data out ---------------------------------------------------------------------------
-    def download(self, first=0, count=None, want_conf=False, want_mask=False):
+    def download(self, first=0, count=None, want_conf=False, want_mask=False, out=None):
         count = self.batch - first if count is None else count
-        out = np.empty((count, self.height, self.width, 3), np.uint8)
+        if out is None:
+            out = np.empty((count, self.height, self.width, 3), np.uint8)
+        elif out.shape != (count, self.height, self.width, 3) or out.dtype != np.uint8 or not out.flags.c_contiguous:
+            raise ValueError("download: out must be a C-contiguous uint8 [%d,%d,%d,3] array"
+                             % (count, self.height, self.width))
         conf = np.empty((count, self.height, self.width), np.float64) if want_conf else None
         msk = np.empty((count, self.height, self.width), np.uint8) if want_mask else None
         _check(load_library().crim_download_batch(

@@ -542,13 +542,23 @@ extern "C" int crim_upload_batch(crim_t* h, int first, int count, const uint8_t*
         return fail(CRIM_ERR_ARG, "crim_upload: row stride smaller than a row");
     HIP_TRY(hipSetDevice(h->device));
     const size_t HW = (size_t)p.H * p.W;
+    // dense inputs travel as one copy each (thousands of per-image copies cost more host time than
+    // the transfer itself)
+    const bool dense_img = row_stride == (ptrdiff_t)p.W * 3 && (count == 1 || image_stride == (ptrdiff_t)(HW * 3));
+    const bool dense_msk = mask_row_stride == (ptrdiff_t)p.W && (count == 1 || mask_image_stride == (ptrdiff_t)HW);
+    if (dense_img)
+        HIP_TRY(hipMemcpyAsync(p.bgr + (size_t)first * HW * 3, bgr, (size_t)count * HW * 3, hipMemcpyHostToDevice, h->stream));
+    if (dense_msk)
+        HIP_TRY(hipMemcpyAsync(p.mask + (size_t)first * HW, mask, (size_t)count * HW, hipMemcpyHostToDevice, h->stream));
     for (int i = 0; i < count; ++i) {
-        HIP_TRY(hipMemcpy2DAsync(p.bgr + (size_t)(first + i) * HW * 3, (size_t)p.W * 3,
-                                 bgr + (ptrdiff_t)i * image_stride, (size_t)row_stride,
-                                 (size_t)p.W * 3, p.H, hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(hipMemcpy2DAsync(p.mask + (size_t)(first + i) * HW, (size_t)p.W,
-                                 mask + (ptrdiff_t)i * mask_image_stride, (size_t)mask_row_stride,
-                                 (size_t)p.W, p.H, hipMemcpyHostToDevice, h->stream));
+        if (!dense_img)
+            HIP_TRY(hipMemcpy2DAsync(p.bgr + (size_t)(first + i) * HW * 3, (size_t)p.W * 3,
+                                     bgr + (ptrdiff_t)i * image_stride, (size_t)row_stride,
+                                     (size_t)p.W * 3, p.H, hipMemcpyHostToDevice, h->stream));
+        if (!dense_msk)
+            HIP_TRY(hipMemcpy2DAsync(p.mask + (size_t)(first + i) * HW, (size_t)p.W,
+                                     mask + (ptrdiff_t)i * mask_image_stride, (size_t)mask_row_stride,
+                                     (size_t)p.W, p.H, hipMemcpyHostToDevice, h->stream));
     }
     const int rc = init_images(h, first, count);
     if (rc) return rc;
@@ -569,15 +579,38 @@ extern "C" int crim_upload_automask(crim_t* h, int first, int count, const uint8
                     threshold, border_width, dilation_size);
     HIP_TRY(hipSetDevice(h->device));
     const size_t HW = (size_t)p.H * p.W;
-    for (int i = 0; i < count; ++i)
-        HIP_TRY(hipMemcpy2DAsync(p.bgr + (size_t)(first + i) * HW * 3, (size_t)p.W * 3,
-                                 bgr + (ptrdiff_t)i * image_stride, (size_t)row_stride,
-                                 (size_t)p.W * 3, p.H, hipMemcpyHostToDevice, h->stream));
+    if (row_stride == (ptrdiff_t)p.W * 3 && (count == 1 || image_stride == (ptrdiff_t)(HW * 3)))
+        HIP_TRY(hipMemcpyAsync(p.bgr + (size_t)first * HW * 3, bgr, (size_t)count * HW * 3, hipMemcpyHostToDevice, h->stream));
+    else
+        for (int i = 0; i < count; ++i)
+            HIP_TRY(hipMemcpy2DAsync(p.bgr + (size_t)(first + i) * HW * 3, (size_t)p.W * 3,
+                                     bgr + (ptrdiff_t)i * image_stride, (size_t)row_stride,
+                                     (size_t)p.W * 3, p.H, hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(k_build_mask, dim3(p.tnx, p.tny, count), dim3(256), 0, h->stream, p, first,
                        threshold, border_width, dilation_size);
     const int rc = init_images(h, first, count);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
+    return CRIM_OK;
+}
+
+// Page-locked host memory: uploads from it and downloads into it are asynchronous DMA transfers
+// that overlap with other engines' kernels.
+extern "C" int crim_host_alloc(size_t bytes, void** out) {
+    if (!out || !bytes) return fail(CRIM_ERR_ARG, "crim_host_alloc: null argument");
+    *out = nullptr;
+    const hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        *out = nullptr;
+        return fail(e == hipErrorOutOfMemory ? CRIM_ERR_NOMEM : CRIM_ERR_HIP, "crim_host_alloc(%zu): %s", bytes,
+                    hipGetErrorString(e));
+    }
+    return CRIM_OK;
+}
+
+extern "C" int crim_host_free(void* ptr) {
+    if (!ptr) return CRIM_OK;
+    HIP_TRY(hipHostFree(ptr));
     return CRIM_OK;
 }
 

@@ -92,6 +92,13 @@ int crim_upload_automask(crim_t* h, int first, int count, const uint8_t* bgr, pt
 /* Same, from dense device buffers ([count][H][W][3] and [count][H][W]) on the engine's GPU. */
 int crim_upload_device(crim_t* h, int first, int count, const void* d_bgr, const void* d_mask);
 
+/* Page-locked host memory (hipHostMalloc / hipHostFree): uploads from and downloads into it are
+ * DMA transfers that overlap with the kernels of other engines, which is how a host that streams
+ * batches hides PCIe behind the fill loop.  No counterpart in the reference (its images never
+ * leave host memory). */
+int crim_host_alloc(size_t bytes, void** out);
+int crim_host_free(void* ptr);
+
 /* inpaint() (:40-88): runs the loop until every image's mask is empty, or until max_iters
  * iterations have been executed in this call (max_iters <= 0: no limit).  iters_done receives
  * the largest per-image iteration count so far, remaining the total masked pixels left. */
