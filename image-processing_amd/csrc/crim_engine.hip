@@ -275,7 +275,7 @@ static bool has_fast_search(int P) { return P >= 3 && P <= 15 && (P & 1); }
 
 // Tile-list rebuild: stale entries only cost a skipped lookup, so it runs rarely.
 static void launch_compact(const Params& p, hipStream_t s) {
-    hipLaunchKernelGGL(k_tiles, dim3(p.B), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(k_tiles, dim3(p.B), dim3(1024), 0, s, p);
 }
 
 static size_t priority_lds_bytes(const Params& p) {
@@ -303,7 +303,9 @@ static void launch_priority(const Params& p, hipStream_t s) {
     }
 }
 
-#define COMPACT_PERIOD 16
+// Iterations between two ordered rebuilds of the tile list (stale entries only cost a skipped
+// lookup; a rebuild walks every tile of the image, so large images rebuild less often).
+static int compact_period(const Params& p) { return p.tnx * p.tny > 1024 ? 64 : 16; }
 
 // One iteration of criminisi_inpainter.py:51-83 as four dependent launches.  ev0/ev1, when
 // given, bracket the search launch.
@@ -320,9 +322,10 @@ static void launch_iteration(const Params& p, hipStream_t s, hipEvent_t ev0 = nu
 static int build_graph(Lane& ln, int iters, GraphSet* out) {
     hipGraph_t graph = nullptr;
     HIP_TRY(hipStreamBeginCapture(ln.stream, hipStreamCaptureModeThreadLocal));
+    const int period = compact_period(ln.prm);
     for (int i = 0; i < iters; ++i) {
-        if (i > 0 && i % COMPACT_PERIOD == 0) launch_compact(ln.prm, ln.stream);
         launch_iteration(ln.prm, ln.stream);
+        if ((i + 1) % period == 0) launch_compact(ln.prm, ln.stream);
     }
     HIP_TRY(hipStreamEndCapture(ln.stream, &graph));
     hipGraphExec_t exec = nullptr;
@@ -359,7 +362,7 @@ static void init_geometry(Params& p, int batch, int H, int W, int patch_size, un
         const char* e = getenv("CRIM_PIPE_T");
         p.pipe_t = e ? atoi(e) : 8;
         e = getenv("CRIM_PIPE_MIN_BLOCKS");
-        p.pipe_min_blocks = e ? atoi(e) : 1024;
+        p.pipe_min_blocks = e ? atoi(e) : 512;
     }
     // priority waves per image: a wave's fixed cost (state, set-up: about 3 us) is shared by the tiles it
     // walks, so large batches, which fill the GPU anyway, get few waves per image
@@ -719,7 +722,7 @@ static int run_split(crim_engine* h, long max_iters) {
         if (max_iters > 0) need = std::min(need, max_iters - done);
         if (need <= 0) break;
         for (long it = 0; it < need; ++it) {
-            if ((done + it) > 0 && (done + it) % COMPACT_PERIOD == 0) launch_compact(p, ln.stream);
+            if ((done + it) > 0 && (done + it) % compact_period(p) == 0) launch_compact(p, ln.stream);
             launch_priority(p, ln.stream);
             hipLaunchKernelGGL(k_select, dim3(p.B), dim3(256), 0, ln.stream, p);
             for (int part = 0; part < parts; ++part) {
@@ -841,7 +844,7 @@ extern "C" int crim_run(crim_t* h, long max_iters, long* iters_done, long* remai
             if (profile && !solo) {
                 // as the loop runs in production: the lanes overlap, every search launch bracketed
                 for (long i = 0; i < need; ++i) {
-                    if ((ln.done + i) > 0 && (ln.done + i) % COMPACT_PERIOD == 0) launch_compact(lp, ln.stream);
+                    if ((ln.done + i) > 0 && (ln.done + i) % compact_period(p) == 0) launch_compact(lp, ln.stream);
                     if (2 * h->ev_used == (int)h->ev.size()) {
                         hipEvent_t a = nullptr, b = nullptr;
                         HIP_TRY(hipEventCreate(&a));
@@ -859,7 +862,7 @@ extern "C" int crim_run(crim_t* h, long max_iters, long* iters_done, long* remai
                 // one iteration per round so that the number of live images per launch is known
                 const double evals = (double)live * (double)std::max(p.H - p.P + 1, 0) * (double)std::max(p.W - p.P + 1, 0);
                 h->ev_evals[h->ev_used] = evals;
-                if (ln.done > 0 && ln.done % COMPACT_PERIOD == 0) launch_compact(lp, ln.stream);
+                if (ln.done > 0 && ln.done % compact_period(p) == 0) launch_compact(lp, ln.stream);
                 launch_iteration(lp, ln.stream, h->ev[2 * h->ev_used], h->ev[2 * h->ev_used + 1]);
                 ++h->ev_used;
                 // the bracketed launch must not share the GPU with another lane's kernels
@@ -871,7 +874,7 @@ extern "C" int crim_run(crim_t* h, long max_iters, long* iters_done, long* remai
                 ln.done += 1;
             } else if (eager) {
                 for (long i = 0; i < need; ++i) {
-                    if ((ln.done + i) > 0 && (ln.done + i) % COMPACT_PERIOD == 0) launch_compact(lp, ln.stream);
+                    if ((ln.done + i) > 0 && (ln.done + i) % compact_period(p) == 0) launch_compact(lp, ln.stream);
                     launch_iteration(lp, ln.stream);
                 }
                 ln.done += need;
@@ -1197,7 +1200,7 @@ extern "C" int crim_inpaint_noalloc(int H, int W, int patch_size, int device, co
         need = std::min(need, 4096L);
         prev_remaining = st.remaining;
         for (long i = 0; i < need; ++i) {
-            if ((done + i) > 0 && (done + i) % COMPACT_PERIOD == 0) launch_compact(p, s);
+            if ((done + i) > 0 && (done + i) % compact_period(p) == 0) launch_compact(p, s);
             launch_iteration(p, s);
         }
         done += need;

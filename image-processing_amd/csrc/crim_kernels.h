@@ -532,29 +532,47 @@ __device__ __forceinline__ bool better_prio(double pa, int ia, double pb, int ib
 // to visit.  A tile is appended when its count leaves zero and stays listed, possibly with a zero
 // count or twice, until the next rebuild; visiting such an entry is harmless.
 
-// Rebuilds the tile list from the counts (one block per image).
-__global__ __launch_bounds__(256) void k_tiles(Params p) {
+// Rebuilds the tile list from the counts (one block of 1024 threads per image).
+__global__ __launch_bounds__(1024) void k_tiles(Params p) {
     const int b = p.b0 + blockIdx.x;
     ImgState* st = p.st + b;
     if (!st->live) return;
     // Ordered compaction (row-major tile order): neighbouring list entries are neighbouring tiles,
     // whose staged regions overlap, and the priority stage visits neighbouring entries together.
-    __shared__ unsigned s_w[4];
+    // A thread takes 4 consecutive tiles per trip (a 4096 x 4096 image has 65536 of them).
+    __shared__ unsigned s_w[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nt = p.tnx * p.tny;
     const int* tf = p.tfront + (size_t)b * nt;
     int* tl = p.tlist + (size_t)b * p.tcap;
     unsigned base = 0;
-    for (int t0 = 0; t0 < nt; t0 += 256) {
-        const int t = t0 + tid;
-        const bool on = t < nt && tf[t] > 0;
-        const unsigned long long bal = __ballot(on);
-        if (lane == 0) s_w[wv] = (unsigned)__popcll(bal);
+    for (int t0 = 0; t0 < nt; t0 += 4096) {
+        const int t = t0 + 4 * tid;
+        int on[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) on[k] = (t + k < nt && tf[imin(t + k, nt - 1)] > 0) ? 1 : 0;
+        const unsigned mine = (unsigned)(on[0] + on[1] + on[2] + on[3]);
+        // inclusive scan over the wave
+        unsigned incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned o = __shfl_up(incl, off);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) s_w[wv] = incl;
         __syncthreads();
-        unsigned off = base;
-        for (int w = 0; w < wv; ++w) off += s_w[w];
-        if (on) tl[off + __popcll(bal & ((1ull << lane) - 1ull))] = t;
-        base += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        unsigned off = base + incl - mine;
+        unsigned total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const unsigned c = s_w[w];
+            if (w < wv) off += c;
+            total += c;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (on[k]) tl[off++] = t + k;
+        base += total;
         __syncthreads();
     }
     if (tid == 0) st->tcount = base;
