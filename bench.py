@@ -63,11 +63,14 @@ def host_cores():
     return max(1, n)
 
 
-def make_batch(batch, h, w, config_id, first_index, colour):
+def make_batch(batch, h, w, config_id, first_index, colour, indices=None):
     """Seeded synthetic images and masks (seed = 1000 * config + global image index), generated on
     a few host processes (forked before this process touches the GPU)."""
     import multiprocessing as mp
-    tasks = [(h, w, 1000 * config_id + first_index + i, colour) for i in range(batch)]
+    if indices is None:
+        indices = range(first_index, first_index + batch)
+    tasks = [(h, w, 1000 * config_id + i, colour) for i in indices]
+    batch = len(tasks)
     imgs = np.empty((batch, h, w, 3), np.uint8)
     masks = np.empty((batch, h, w), np.uint8)
     workers = max(1, min(host_cores(), batch // 8))
@@ -248,6 +251,36 @@ def config_512_batch(capi, torch, device, imgs, masks, steps):
             "roofline_note": "search launches of the first 200 lock-step iterations, each alone on the GPU"}
 
 
+def sharded_512(capi, torch, dist, device, imgs, masks, world, backend):
+    """configs[2] as BASELINE words it: a FIXED set of 800 512x512 images divided among the ranks
+    (image i on rank i mod N, no data-path collective); every rank fills its share, the slowest
+    rank's time counts (strong scaling)."""
+    n = len(imgs)
+    d_img = torch.from_numpy(imgs).cuda()
+    d_mask = torch.from_numpy(masks).cuda()
+    d_out = torch.empty_like(d_img)
+    with capi.Engine(512, 512, 9, batch=n, device=device, flags=capi.FLAG_NO_TRACE) as eng:
+        def step():
+            eng.upload_device(d_img.data_ptr(), d_mask.data_ptr())
+            eng.run()
+            eng.download_device(d_out.data_ptr())
+        step()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        step()
+        dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    return {"workload": "BASELINE configs[2]: a fixed set of 800 synthetic 512x512 false-colour images, 10 %% masks, "
+                        "patch_size 9, image i on rank i mod %d; inputs and outputs resident in HBM" % world,
+            "images": 800, "ranks": world, "images_on_this_rank": n, "scaling": "strong",
+            "images_per_s": 800.0 / dt, "ms": 1e3 * dt}
+
+
 def config_large(capi, device, side, patch, config_index, profile_iters=1500):
     """configs[3] / configs[4]: one side x side false-colour image with a centred hole of a quarter
     of the frame, run to completion."""
@@ -345,6 +378,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-host-io", action="store_true")
+    ap.add_argument("--no-split", action="store_true", help="skip the RCCL split-search workers of configs[4]")
+    ap.add_argument("--split-iters", type=int, default=2000)
     ap.add_argument("--colour", action="store_true",
                     help="false-colour images (5-plane search) instead of the grey ones of BASELINE configs[1]; "
                          "side measurement, run with --no-roofline")
@@ -356,10 +391,30 @@ def main():
     distributed = world > 1
     want = set(int(c) for c in args.configs.split(",") if c.strip() != "") if world == 1 else set()
     B = args.batch
+
+    # The intra-image split search of configs[4] drives RCCL through the engine library, which must
+    # not share a process with PyTorch's bundled ROCm runtime: one worker process per rank, started
+    # here -- before this process touches the GPU -- and released through a file further down.
+    split_proc = None
+    split_dir = None
+    if (world > 1 or 4 in want) and not args.no_split:
+        import crim_split_worker as sw
+        split_dir = os.path.join(os.environ.get("TMPDIR", "/tmp"),
+                                 "crim_split_%s_%s" % (os.environ.get("MASTER_PORT", "solo"),
+                                                       os.environ.get("TORCHELASTIC_RUN_ID", str(os.getppid()))))
+        if rank == 0:
+            import shutil
+            shutil.rmtree(split_dir, ignore_errors=True)
+        os.makedirs(split_dir, exist_ok=True)
+        dev = int(os.environ.get("BENCH_DEVICE", local_rank))
+        split_proc = sw.launch_worker(rank, world, dev, split_dir, size=4096, patch=9, iters=args.split_iters)
+
     imgs, masks = make_batch(B, H, W, CONFIG_ID, rank * B, args.colour)
     imgs512 = masks512 = None
     if 2 in want:
         imgs512, masks512 = make_batch(800, 512, 512, 3, 0, True)
+    elif world > 1:
+        imgs512, masks512 = make_batch(0, 512, 512, 3, 0, True, indices=range(rank, 800, world))
 
     # CPU baseline first (rank 0, single-GPU runs only), before this process touches the GPU:
     # the worker pool forks.
@@ -520,6 +575,36 @@ def main():
             cfgs["configs[4]"]["multi_gpu_note"] = ("one GPU; the intra-image split over N GPUs (RCCL all-gather of 16 B "
                                                     "per rank per iteration) is measured by `bench.py --gpus N`")
         result["configs"] = cfgs
+
+    if distributed:
+        # every rank takes part: the fixed 800-image set of configs[2], sharded
+        sh = sharded_512(capi, torch, dist, local_rank, imgs512, masks512, world, backend)
+        if rank == 0:
+            result.setdefault("configs", {})["configs[2] sharded"] = sh
+
+    if split_proc is not None:
+        import crim_split_worker as sw
+        # this process's GPU work is over: let the split workers have the GPUs
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        if distributed:
+            dist.barrier()
+        if rank == 0:
+            sw.release(split_dir)
+            res = sw.summarise(sw.collect(split_dir, world, 600.0))
+            res["note"] = ("configs[4], %d rank(s): every rank holds a replica of the 4096x4096 image, scores its share of "
+                           "the window-origin rows and the ranks' best windows (16 B each) are exchanged by one RCCL "
+                           "all-gather per iteration; us_per_iteration is the slowest rank's, over %d iterations after "
+                           "32 warm-up ones; single_gpu_us_per_iteration is the unsplit engine on rank 0's GPU over the "
+                           "same iterations (the crossover is where the former drops below the latter)"
+                           % (world, args.split_iters))
+            result.setdefault("configs", {}).setdefault("configs[4]", {})["split_rccl"] = res
+        try:
+            split_proc.wait(timeout=660)
+        except Exception:                                   # noqa: BLE001
+            split_proc.kill()
+        if distributed:
+            dist.barrier()
 
     if rank == 0:
         print(json.dumps(result))

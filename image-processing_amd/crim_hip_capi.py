@@ -77,6 +77,8 @@ def load_library():
     lib.crim_split_unique_id.argtypes = [vp]
     lib.crim_split_init.restype = ci
     lib.crim_split_init.argtypes = [vp, ci, ci, vp]
+    lib.crim_split_info.restype = ci
+    lib.crim_split_info.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci)]
     lib.crim_run.restype = ci
     lib.crim_run.argtypes = [vp, cl, ctypes.POINTER(cl), ctypes.POINTER(cl)]
     lib.crim_download.restype = ci
@@ -242,6 +244,12 @@ class Engine:
     def split_init(self, nranks, rank, unique_id):
         buf = ctypes.create_string_buffer(bytes(unique_id), 128)
         _check(load_library().crim_split_init(self._h, int(nranks), int(rank), buf))
+
+    def split_info(self):
+        """(ranks, rank) as the RCCL communicator reports them."""
+        n, r = ctypes.c_int(), ctypes.c_int()
+        _check(load_library().crim_split_info(self._h, ctypes.byref(n), ctypes.byref(r)))
+        return n.value, r.value
 
     # -- loop -------------------------------------------------------------------------------
     def run(self, max_iters=0):

@@ -26,6 +26,44 @@ def _write_png(path, bgr):
     Image.fromarray(np.ascontiguousarray(bgr[:, :, ::-1])).save(path)
 
 
+class _FrameDumper:
+    """Rebuilds the working image iteration by iteration from trace records (the update rule of
+    criminisi_inpainter.py:267-308: masked pixels of the target patch take the source patch's
+    pixels, then the patch's mask is cleared) and writes results/working_image_<c>.png for the
+    state BEFORE iteration c, as the reference does at :55-57, on worker threads."""
+
+    def __init__(self, image, mask_u8, patch_size, workers=4):
+        from concurrent.futures import ThreadPoolExecutor
+        self.img = np.array(image, dtype=np.uint8, copy=True)
+        self.msk = np.array(mask_u8, dtype=np.uint8, copy=True)
+        self.half = (int(patch_size) - 1) // 2
+        self.c = 0
+        self.pool = ThreadPoolExecutor(max_workers=workers)
+        self.pending = []
+
+    def emit_then_apply(self, rec):
+        self.pending.append(self.pool.submit(_write_png, 'results/working_image_' + str(self.c) + '.png',
+                                             self.img.copy()))
+        self.c += 1
+        H, W = self.msk.shape
+        tr, tc, sy, sx = int(rec['tr']), int(rec['tc']), int(rec['sy']), int(rec['sx'])
+        r0, r1 = max(0, tr - self.half), min(tr + self.half, H - 1)
+        c0, c1 = max(0, tc - self.half), min(tc + self.half, W - 1)
+        ph, pw = r1 - r0 + 1, c1 - c0 + 1
+        src = self.img[sy:sy + ph, sx:sx + pw].copy()
+        sel = self.msk[r0:r1 + 1, c0:c1 + 1] != 0
+        self.img[r0:r1 + 1, c0:c1 + 1][sel] = src[sel]
+        self.msk[r0:r1 + 1, c0:c1 + 1] = 0
+        if len(self.pending) > 64:          # bound the frames held in memory
+            self.pending.pop(0).result()
+
+    def close(self):
+        for f in self.pending:
+            f.result()
+        self.pending = []
+        self.pool.shutdown(wait=True)
+
+
 class Criminisi_Inpainter():
     '''
     Criminisi (2004) exemplar-based inpainting on an AMD MI355X.
@@ -95,37 +133,34 @@ class Criminisi_Inpainter():
         self._engine = eng
         eng.upload(img, mask_u8)
 
-        if self.verbose and not self.show_progress:
-            # The per-iteration lines (:67-69, :76-77) are printed for a chunk of iterations at a
-            # time from the device's per-iteration records, so that the fill loop keeps replaying
-            # graphs; 'Time to find best' is the chunk's wall time divided by its iterations.
+        if self.verbose or self.show_progress:
+            # Neither side effect puts the host into the loop: the fill keeps replaying graphs, a
+            # chunk of iterations per call, and both are produced behind it from the device's
+            # per-iteration records.  verbose (:67-69, :76-77): the lines of a chunk are printed
+            # together; 'Time to find best' is the chunk's wall time divided by its iterations.
+            # show_progress (:55-57): frame c is the working image before iteration c's update, i.e.
+            # the input with the first c patch copies of the trace applied -- rebuilt on the host
+            # and encoded by worker threads while the GPU runs the next chunk.
+            frames = _FrameDumper(img, mask_u8, self.patch_size) if self.show_progress else None
             shown = 0
-            while True:
-                chunk_start = time.time()
-                _, remaining = eng.run(max_iters=self.VERBOSE_CHUNK)
-                recs = eng.trace(0)
-                per_iter = (time.time() - chunk_start) / max(len(recs) - shown, 1)
-                for r in recs[shown:]:
-                    print('Time to find best: %.2f seconds' % per_iter)
-                    print('%d of %d completed' % (total - int(r['remaining']), total))
-                shown = len(recs)
-                if remaining == 0:
-                    break
-        elif self.show_progress:
-            # A frame before every iteration's update needs the host in the loop: one iteration per call.
-            c = 0
-            while True:
-                if self.show_progress:
-                    frame, _, _ = eng.download()
-                    _write_png('results/working_image_' + str(c) + '.png', frame[0])
-                find_start_time = time.time()
-                _, remaining = eng.run(max_iters=1)
-                if self.verbose:
-                    print('Time to find best: %.2f seconds' % (time.time() - find_start_time))
-                    print('%d of %d completed' % (total - remaining, total))
-                if remaining == 0:
-                    break
-                c += 1
+            try:
+                while True:
+                    chunk_start = time.time()
+                    _, remaining = eng.run(max_iters=self.VERBOSE_CHUNK)
+                    recs = eng.trace(0)
+                    per_iter = (time.time() - chunk_start) / max(len(recs) - shown, 1)
+                    for r in recs[shown:]:
+                        if frames is not None:
+                            frames.emit_then_apply(r)
+                        if self.verbose:
+                            print('Time to find best: %.2f seconds' % per_iter)
+                            print('%d of %d completed' % (total - int(r['remaining']), total))
+                    shown = len(recs)
+                    if remaining == 0:
+                        break
+            finally:
+                if frames is not None:
+                    frames.close()
         else:
             eng.run()
 

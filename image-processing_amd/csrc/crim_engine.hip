@@ -181,6 +181,8 @@ struct RcclApi {
     decltype(&ncclAllGather) all_gather = nullptr;
     decltype(&ncclCommDestroy) comm_destroy = nullptr;
     decltype(&ncclGetErrorString) error_string = nullptr;
+    decltype(&ncclCommCount) comm_count = nullptr;
+    decltype(&ncclCommUserRank) comm_user_rank = nullptr;
 };
 RcclApi g_rccl;
 std::mutex g_rccl_mutex;
@@ -196,6 +198,8 @@ int load_rccl() {
     g_rccl.all_gather = (decltype(&ncclAllGather))dlsym(lib, "ncclAllGather");
     g_rccl.comm_destroy = (decltype(&ncclCommDestroy))dlsym(lib, "ncclCommDestroy");
     g_rccl.error_string = (decltype(&ncclGetErrorString))dlsym(lib, "ncclGetErrorString");
+    g_rccl.comm_count = (decltype(&ncclCommCount))dlsym(lib, "ncclCommCount");
+    g_rccl.comm_user_rank = (decltype(&ncclCommUserRank))dlsym(lib, "ncclCommUserRank");
     if (!g_rccl.get_unique_id || !g_rccl.comm_init_rank || !g_rccl.all_gather || !g_rccl.comm_destroy)
         return fail(CRIM_ERR_STATE, "split search: librccl.so lacks a required symbol");
     g_rccl.lib = lib;
@@ -777,6 +781,17 @@ extern "C" int crim_split_init(crim_t* h, int nranks, int rank, const void* uniq
         return fail(CRIM_ERR_HIP, "ncclCommInitRank: %s", g_rccl.error_string ? g_rccl.error_string(r) : "error");
     h->split_parts = nranks;
     h->split_rank = rank;
+    return CRIM_OK;
+}
+
+// What the communicator itself reports (not what crim_split_init was told).
+extern "C" int crim_split_info(crim_t* h, int* nranks, int* rank) {
+    if (!h || !nranks || !rank) return fail(CRIM_ERR_ARG, "crim_split_info: null argument");
+    if (!h->comm) return fail(CRIM_ERR_STATE, "crim_split_info: crim_split_init has not been called");
+    if (!g_rccl.comm_count || !g_rccl.comm_user_rank)
+        return fail(CRIM_ERR_STATE, "crim_split_info: librccl.so lacks ncclCommCount / ncclCommUserRank");
+    if (g_rccl.comm_count(h->comm, nranks) != ncclSuccess || g_rccl.comm_user_rank(h->comm, rank) != ncclSuccess)
+        return fail(CRIM_ERR_HIP, "crim_split_info: RCCL query failed");
     return CRIM_OK;
 }
 

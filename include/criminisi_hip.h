@@ -117,6 +117,8 @@ int crim_run(crim_t* h, long max_iters, long* iters_done, long* remaining);
 int crim_split_virtual(crim_t* h, int nparts);
 int crim_split_unique_id(void* out128);
 int crim_split_init(crim_t* h, int nranks, int rank, const void* unique_id128);
+/* Size and rank of the RCCL communicator as RCCL itself reports them (after crim_split_init). */
+int crim_split_info(crim_t* h, int* nranks, int* rank);
 
 /* working_image (:88), confidence and working_mask after the run; null outputs are skipped. */
 int crim_download(crim_t* h, uint8_t* bgr_out, double* conf_out, uint8_t* mask_out);

@@ -421,6 +421,20 @@ def test_shim_verbose_and_show_progress_side_effects(tmp_path, monkeypatch, caps
     out = Criminisi_Inpainter(img, m, patch_size=9, show_progress=True).inpaint()
     assert np.array_equal(out, oout)
     assert sorted(os.listdir('results')) == sorted('working_image_%d.png' % c for c in range(n))
+    # frame c is the working image before iteration c's update
+    from PIL import Image
+    for c in (0, 1, n // 2, n - 1):
+        frame = np.asarray(Image.open('results/working_image_%d.png' % c).convert("RGB"))[:, :, ::-1]
+        want, _ = c_oracle.replay(img, m, 9, otr, c)
+        assert np.array_equal(frame, want), c
+    # both side effects together, chunks of 3 iterations
+    for f in os.listdir('results'):
+        os.remove(os.path.join('results', f))
+    capsys.readouterr()
+    out = Criminisi_Inpainter(img, m, patch_size=9, verbose=True, show_progress=True).inpaint()
+    assert np.array_equal(out, oout)
+    assert len(capsys.readouterr().out.splitlines()) == 2 * n + 1
+    assert len(os.listdir('results')) == n
 
 
 def test_full_size_properties_256():
