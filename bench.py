@@ -206,6 +206,11 @@ def config_dataset(capi, device, steps):
             iters = np.array([eng.iterations(i) for i in range(B)])
         roof, evals_s = search_roofline(capi, 256, 256, 9, B, lambda e: e.upload_automask(imgs, dilation_size=4),
                                         "k_search_pipe<9, true>", 5, False, device)
+        # the stage that follows the inpainter in the reference's pipeline (filter_noise, utils.py:106-138)
+        capi.filter_noise(out[:4])
+        t0 = time.perf_counter()
+        capi.filter_noise(out, median_ksize=3, nlm_h=7, apply_sharpening=True)
+        nf_dt = time.perf_counter() - t0
     finally:
         capi.pinned_free(imgs)
         capi.pinned_free(out)
@@ -216,7 +221,13 @@ def config_dataset(capi, device, steps):
             "images": B, "images_per_s_incl_host_io": B / dt, "ms_per_batch": 1e3 * dt,
             "iterations_per_image_mean": float(iters.mean()), "iterations_per_image_max": int(iters.max()),
             "us_per_lockstep_iteration": 1e6 * dt / int(iters.max()),
-            "evals_per_s_per_gpu": evals_s, "roofline": roof}
+            "evals_per_s_per_gpu": evals_s, "roofline": roof,
+            "next_stage_filter_noise": {
+                "what": "filter_noise(median 3, non-local means h=7 / hColor=1, template 9, search 31, sharpening) "
+                        "of src/utils.py:106-138 on the %d inpainted images, host arrays in and out" % B,
+                "images_per_s_incl_host_io": B / nf_dt, "ms_per_batch": 1e3 * nf_dt,
+                # per pixel 2 runs x 961 candidates x 81 squared differences (two 16-bit lanes per dword)
+                "window_differences_per_s": B * 256 * 256 * 961 * 81 * 3 / nf_dt}}
 
 
 def config_512_batch(capi, torch, device, imgs, masks, steps):

@@ -102,6 +102,12 @@ def load_library():
     lib.crim_host_free.argtypes = [vp]
     lib.crim_inpaint_noalloc.restype = ci
     lib.crim_inpaint_noalloc.argtypes = [ci, ci, ci, ci, vp, vp, vp, ctypes.POINTER(cl)]
+    lib.crim_filter_noise.restype = ci
+    lib.crim_filter_noise.argtypes = [ci, ci, ci, ci, vp, vp, ci, ctypes.c_float, ci]
+    lib.crim_filter_noise_device.restype = ci
+    lib.crim_filter_noise_device.argtypes = [ci, ci, ci, ci, vp, vp, ci, ctypes.c_float, ci]
+    lib.crim_filter_noise_engine.restype = ci
+    lib.crim_filter_noise_engine.argtypes = [vp, ci, ctypes.c_float, ci]
     lib.crim_peek_fields.restype = ci
     lib.crim_peek_fields.argtypes = [vp, ci, vp, vp, vp]
     _lib = lib
@@ -148,6 +154,25 @@ def pinned_empty(shape, dtype=np.uint8):
 
 def pinned_free(array):
     _check(load_library().crim_host_free(ctypes.c_void_p(array.ctypes.data)))
+
+
+def filter_noise(images, median_ksize=3, nlm_h=7, apply_sharpening=True, device=0):
+    """The reference's filter_noise (src/utils.py:106-138) on the GPU for one image [H,W,3] or a
+    stack [n,H,W,3] of uint8 BGR images; returns the same shape."""
+    lib = load_library()
+    if lib.crim_device_count() <= 0:
+        raise CriminisiHipError(CRIM_ERR_HIP, "no HIP device visible: the noise filter runs only on an AMD GPU")
+    img = np.asarray(images)
+    single = img.ndim == 3
+    if single:
+        img = img[None]
+    if img.ndim != 4 or img.shape[3] != 3 or img.dtype != np.uint8:
+        raise ValueError("filter_noise: expected uint8 images [n,H,W,3] in BGR order")
+    img = np.ascontiguousarray(img)
+    out = np.empty_like(img)
+    _check(lib.crim_filter_noise(int(device), img.shape[0], img.shape[1], img.shape[2], img.ctypes.data,
+                                 out.ctypes.data, int(median_ksize), float(nlm_h), 1 if apply_sharpening else 0))
+    return out[0] if single else out
 
 
 NOALLOC_MAX_PIXELS = 512 * 512
@@ -277,6 +302,11 @@ class Engine:
         count = self.batch - first if count is None else count
         _check(load_library().crim_download_device(self._h, int(first), int(count),
                                                    ctypes.c_void_p(int(d_out_ptr))))
+
+    def filter_noise(self, median_ksize=3, nlm_h=7, apply_sharpening=True):
+        """filter_noise (src/utils.py:106-138) in place on the engine's working images."""
+        _check(load_library().crim_filter_noise_engine(self._h, int(median_ksize), float(nlm_h),
+                                                       1 if apply_sharpening else 0))
 
     def iterations(self, index=0):
         n = ctypes.c_long()

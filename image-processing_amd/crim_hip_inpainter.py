@@ -208,6 +208,14 @@ def inpaint_image(image, patch_size=9, dilation_size=4, device=0):
     return out[0]
 
 
+def filter_noise(image, median_ksize=3, nlm_h=7, apply_sharpening=True, device=0):
+    """Mirror of /root/reference/src/utils.py:106-138 (`filter_noise`): median blur, non-local
+    means in Lab (h = nlm_h on L, 1 on a and b, template 9, search 31) and Laplacian sharpening,
+    all on the GPU."""
+    return capi.filter_noise(image, median_ksize=median_ksize, nlm_h=nlm_h,
+                             apply_sharpening=apply_sharpening, device=device)
+
+
 def inpaint_many(images, masks, patch_size=9, device=0, batch=None):
     """Inpaints a list/array of same-shaped images as lock-step batches on one GPU: the loop of
     /root/reference/scripts/main.py:44-58 around Criminisi_Inpainter(...).inpaint(), without the

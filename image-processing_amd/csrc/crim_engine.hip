@@ -1232,3 +1232,177 @@ extern "C" int crim_inpaint_noalloc(int H, int W, int patch_size, int device, co
                     "(the reference loop would not terminate)", st.remaining);
     return CRIM_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// Noise-filter stage (filter_noise, /root/reference/src/utils.py:106-138)
+// ------------------------------------------------------------------------------------------
+#include "crim_filters.h"
+
+namespace {
+
+struct NfHostTables {
+    uint16_t yf[512];       // LabToYF_b: (y, f(y)) per 8-bit L in units of 1/16384, float32 arithmetic
+    int coef_inv[9];        // XYZ -> linear BGR times the white point, 12 bit
+};
+
+const NfHostTables& nf_host_tables() {
+    static NfHostTables t;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const int base = 1 << 14;
+        for (int i = 0; i < 256; ++i) {
+            int y, ify;
+            if (i <= 20) {
+                y = round_half_even((double)((float)(i * base * 20 * 9) / (float)(17 * 29 * 29 * 29)));
+                const float a = (float)16 / (float)116, b = (float)(i * 5) / (float)(3 * 17 * 29);
+                const float s = a + b;
+                ify = round_half_even((double)((float)base * s));
+            } else {
+                const float p = (float)(i * 100 * base) / (float)(255 * 116);
+                const float q = (float)(16 * base) / (float)116;
+                const float fy = p + q;
+                ify = round_half_even((double)fy);
+                const float f2 = fy * fy;
+                const float f3 = f2 * fy;
+                y = round_half_even((double)(f3 / (float)(base * base)));
+            }
+            t.yf[2 * i] = (uint16_t)y;
+            t.yf[2 * i + 1] = (uint16_t)ify;
+        }
+        static const double m[9] = {3.240479, -1.53715, -0.498535, -0.969256, 1.875991,
+                                    0.041556, 0.055648, -0.204043, 1.057311};
+        static const double wp[3] = {0.950456, 1.0, 1.088754};
+        for (int c = 0; c < 3; ++c)          // output channel c of B,G,R uses the XYZ -> sRGB row 2 - c
+            for (int j = 0; j < 3; ++j) t.coef_inv[3 * c + j] = round_half_even(4096.0 * m[3 * (2 - c) + j] * wp[j]);
+    });
+    return t;
+}
+
+// almost_dist2weight_ of OpenCV's FastNlMeansDenoisingInvoker for 8-bit samples: entry a is the
+// integer weight of the shifted window distance a.
+std::vector<int> nlm_weight_table(float h, int channels, int* shift_out) {
+    const int tsq = NF_TW * NF_TW;
+    int shift = 0;
+    while ((1 << shift) < tsq) ++shift;
+    const double mult = (double)(1 << shift) / tsq;
+    const int max_dist = 255 * 255 * channels;
+    const int n = (int)(max_dist / mult + 1);
+    const int fpm = std::min(2147483647 / (NF_SW * NF_SW * 255), 2147483647);
+    const float hh = h * h * (float)channels;
+    std::vector<int> tab((size_t)n);
+    for (int a = 0; a < n; ++a) {
+        const double dist = a * mult;
+        double w = hh > 0 ? std::exp(-dist / hh) : 1.0;
+        if (std::isnan(w)) w = 1.0;
+        int weight = round_half_even(fpm * w);
+        if (weight < 0.001 * fpm) weight = 0;
+        tab[(size_t)a] = weight;
+    }
+    *shift_out = shift;
+    return tab;
+}
+
+struct NfScratch {
+    uint8_t *l0 = nullptr, *ab0 = nullptr, *l1 = nullptr, *ab1 = nullptr;
+    int *wl = nullptr, *wab = nullptr;
+    uint16_t *cbrt = nullptr, *yf = nullptr;
+    void release() {
+        void* q[] = {l0, ab0, l1, ab1, wl, wab, cbrt, yf};
+        for (void* p : q)
+            if (p) (void)hipFree(p);
+    }
+};
+
+// The three launches of the stage on dense device images [count][H][W][3]; in-place allowed.
+int filter_noise_device(int count, int H, int W, const uint8_t* d_in, uint8_t* d_out, int median_ksize,
+                        float nlm_h, int apply_sharpening, hipStream_t s) {
+    if (median_ksize != 1 && median_ksize != 3 && median_ksize != 5 && median_ksize != 7)
+        return fail(CRIM_ERR_ARG, "crim_filter_noise: median_ksize %d (1, 3, 5 or 7)", median_ksize);
+    if (!(nlm_h >= 0.0f) || nlm_h > 1000.0f) return fail(CRIM_ERR_ARG, "crim_filter_noise: nlm_h %g", (double)nlm_h);
+    const size_t HW = (size_t)H * W, n = (size_t)count;
+    NfScratch sc;
+    hipError_t e = hipSuccess;
+    auto alloc = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
+    int shift_l = 0, shift_ab = 0;
+    const std::vector<int> wl = nlm_weight_table(nlm_h, 1, &shift_l);
+    const std::vector<int> wab = nlm_weight_table(1.0f, 2, &shift_ab);      // hColor=1 (utils.py:125)
+    const LabTables& lt = lab_tables();
+    const NfHostTables& ht = nf_host_tables();
+    alloc((void**)&sc.l0, n * HW);
+    alloc((void**)&sc.ab0, n * HW * 2);
+    alloc((void**)&sc.l1, n * HW);
+    alloc((void**)&sc.ab1, n * HW * 2);
+    alloc((void**)&sc.wl, wl.size() * sizeof(int));
+    alloc((void**)&sc.wab, wab.size() * sizeof(int));
+    alloc((void**)&sc.cbrt, sizeof(lt.cbrt_));
+    alloc((void**)&sc.yf, sizeof(ht.yf));
+    if (e == hipSuccess) e = hipMemcpyAsync(sc.wl, wl.data(), wl.size() * sizeof(int), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(sc.wab, wab.data(), wab.size() * sizeof(int), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(sc.cbrt, lt.cbrt_, sizeof(lt.cbrt_), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(sc.yf, ht.yf, sizeof(ht.yf), hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) {
+        sc.release();
+        return fail(e == hipErrorOutOfMemory ? CRIM_ERR_NOMEM : CRIM_ERR_HIP, "crim_filter_noise: %s", hipGetErrorString(e));
+    }
+    NfTables t;
+    t.cbrt_tab = sc.cbrt;
+    t.yf_tab = sc.yf;
+    memcpy(t.coef_fwd, lt.coef, sizeof(t.coef_fwd));
+    memcpy(t.coef_inv, ht.coef_inv, sizeof(t.coef_inv));
+    const dim3 grid((W + 15) / 16, (H + 15) / 16, count), block(256);
+    switch (median_ksize) {
+        case 1: hipLaunchKernelGGL(k_nf_median_lab<1>, grid, block, 0, s, d_in, sc.l0, sc.ab0, H, W, t); break;
+        case 3: hipLaunchKernelGGL(k_nf_median_lab<3>, grid, block, 0, s, d_in, sc.l0, sc.ab0, H, W, t); break;
+        case 5: hipLaunchKernelGGL(k_nf_median_lab<5>, grid, block, 0, s, d_in, sc.l0, sc.ab0, H, W, t); break;
+        default: hipLaunchKernelGGL(k_nf_median_lab<7>, grid, block, 0, s, d_in, sc.l0, sc.ab0, H, W, t); break;
+    }
+    // length of the tables' non-zero prefix: all a window distance can reach with a weight
+    auto prefix = [](const std::vector<int>& w) { size_t k = w.size(); while (k > 0 && w[k - 1] == 0) --k; return (int)k; };
+    hipLaunchKernelGGL(k_nf_nlm<1>, grid, block, 0, s, sc.l0, sc.l1, H, W, sc.wl, prefix(wl), shift_l);
+    hipLaunchKernelGGL(k_nf_nlm<2>, grid, block, 0, s, sc.ab0, sc.ab1, H, W, sc.wab, prefix(wab), shift_ab);
+    hipLaunchKernelGGL(k_nf_lab2bgr_sharpen, grid, block, 0, s, sc.l1, sc.ab1, d_out, H, W, apply_sharpening ? 1 : 0, t);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    sc.release();
+    if (e != hipSuccess) return fail(CRIM_ERR_HIP, "crim_filter_noise: %s", hipGetErrorString(e));
+    return CRIM_OK;
+}
+
+}  // namespace
+
+extern "C" int crim_filter_noise_device(int device, int count, int H, int W, const void* d_bgr_in, void* d_bgr_out,
+                                        int median_ksize, float nlm_h, int apply_sharpening) {
+    if (!d_bgr_in || !d_bgr_out) return fail(CRIM_ERR_ARG, "crim_filter_noise_device: null argument");
+    if (count < 1 || H < 1 || W < 1) return fail(CRIM_ERR_ARG, "crim_filter_noise_device: bad shape %d x %d x %d", count, H, W);
+    HIP_TRY(hipSetDevice(device));
+    return filter_noise_device(count, H, W, (const uint8_t*)d_bgr_in, (uint8_t*)d_bgr_out, median_ksize, nlm_h,
+                               apply_sharpening, nullptr);
+}
+
+extern "C" int crim_filter_noise(int device, int count, int H, int W, const uint8_t* bgr_in, uint8_t* bgr_out,
+                                 int median_ksize, float nlm_h, int apply_sharpening) {
+    if (!bgr_in || !bgr_out) return fail(CRIM_ERR_ARG, "crim_filter_noise: null argument");
+    if (count < 1 || H < 1 || W < 1) return fail(CRIM_ERR_ARG, "crim_filter_noise: bad shape %d x %d x %d", count, H, W);
+    HIP_TRY(hipSetDevice(device));
+    const size_t bytes = (size_t)count * H * W * 3;
+    uint8_t* d = nullptr;
+    const hipError_t e = hipMalloc((void**)&d, bytes);
+    if (e != hipSuccess)
+        return fail(e == hipErrorOutOfMemory ? CRIM_ERR_NOMEM : CRIM_ERR_HIP, "crim_filter_noise: %s", hipGetErrorString(e));
+    int rc = CRIM_OK;
+    if (hipMemcpy(d, bgr_in, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = fail(CRIM_ERR_HIP, "crim_filter_noise: upload failed");
+    if (!rc) rc = filter_noise_device(count, H, W, d, d, median_ksize, nlm_h, apply_sharpening, nullptr);
+    if (!rc && hipMemcpy(bgr_out, d, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(CRIM_ERR_HIP, "crim_filter_noise: download failed");
+    (void)hipFree(d);
+    return rc;
+}
+
+// filter_noise applied in place to the working images of an engine (after crim_run): the
+// inpaint -> denoise order of process_image (utils.py:216-220) without leaving the device.
+extern "C" int crim_filter_noise_engine(crim_t* h, int median_ksize, float nlm_h, int apply_sharpening) {
+    if (!h) return fail(CRIM_ERR_ARG, "crim_filter_noise_engine: null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    for (auto& ln : h->lanes) HIP_TRY(hipStreamSynchronize(ln.stream));
+    const Params& p = h->prm;
+    return filter_noise_device(p.B, p.H, p.W, p.bgr, p.bgr, median_ksize, nlm_h, apply_sharpening, h->stream);
+}

@@ -1,0 +1,232 @@
+// HIP kernels of the noise-filter stage that follows the inpainter in the reference's pipeline:
+// filter_noise, /root/reference/src/utils.py:106-138 -- cv2.medianBlur (:118),
+// cv2.fastNlMeansDenoisingColored(h, hColor=1, template 9, search 31) (:124-126), Laplacian
+// sharpening with cv2.filter2D(CV_8U) and cv2.subtract (:128-136).  All arithmetic is integer
+// (OpenCV's 8-bit paths are fixed point), so results are compared bit for bit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define NF_TW 9                 // template window of the non-local means (utils.py:126)
+#define NF_SW 31                // search window
+#define NF_TWH (NF_TW / 2)
+#define NF_SWH (NF_SW / 2)
+#define NF_BORDER (NF_TWH + NF_SWH)
+#define NF_TILE 16              // output tile edge of the non-local-means kernel
+#define NF_REGION (NF_TILE + 2 * NF_BORDER)   // 54: staged source region edge
+#define NF_PITCH 80             // LDS pitch in dwords: 16 mod 32, so the 4 rows a wave reads hit each bank twice
+#define NF_WLDS 1024            // weights kept in LDS (the table's non-zero prefix is shorter for h <= 15)
+
+struct NfTables {
+    const uint16_t* cbrt_tab;   // 3072 entries, shared with the inpainter's BGR -> Lab
+    const uint16_t* yf_tab;     // 256 x (y, f(y)) in units of 1/16384
+    int coef_fwd[9];            // BGR -> XYZ / white point, 12 bit
+    int coef_inv[9];            // XYZ -> BGR * white point, 12 bit
+};
+
+// BORDER_REFLECT_101 for any distance (OpenCV's borderInterpolate loops the same way).
+__device__ __forceinline__ int nf_reflect101(int i, int n) {
+    if (n == 1) return 0;
+    const int period = 2 * (n - 1);
+    i %= period;
+    if (i < 0) i += period;
+    return i >= n ? period - i : i;
+}
+__device__ __forceinline__ int nf_clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// Median of k x k (k odd, <= 7) per channel with BORDER_REPLICATE, then linear BGR -> Lab
+// (COLOR_LBGR2Lab: the integer pipeline of the inpainter's Lab with the gamma table i * 8).
+// Writes the L plane and the interleaved (a, b) plane.
+template <int K>
+__global__ __launch_bounds__(256) void k_nf_median_lab(const uint8_t* __restrict__ bgr, uint8_t* __restrict__ lpl,
+                                                       uint8_t* __restrict__ abpl, int H, int W, NfTables t) {
+    const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (x >= W || y >= H) return;
+    const size_t HW = (size_t)H * W;
+    const uint8_t* img = bgr + (size_t)blockIdx.z * HW * 3;
+    int med[3];
+    if (K == 1) {
+        const uint8_t* px = img + ((size_t)y * W + x) * 3;
+        med[0] = px[0]; med[1] = px[1]; med[2] = px[2];
+    } else {
+        constexpr int R = K / 2, N = K * K;
+        uint8_t v[3][N];
+#pragma unroll
+        for (int i = 0; i < K; ++i)
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const int yy = nf_clampi(y + i - R, 0, H - 1), xx = nf_clampi(x + j - R, 0, W - 1);
+                const uint8_t* px = img + ((size_t)yy * W + xx) * 3;
+                v[0][i * K + j] = px[0]; v[1][i * K + j] = px[1]; v[2][i * K + j] = px[2];
+            }
+        // the median is the smallest value with at least (N+1)/2 samples at or below it
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            int lo = 0, hi = 255;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                int cnt = 0;
+#pragma unroll
+                for (int e = 0; e < N; ++e) cnt += v[c][e] <= mid ? 1 : 0;
+                if (cnt >= (N + 1) / 2) hi = mid; else lo = mid + 1;
+            }
+            med[c] = lo;
+        }
+    }
+    const int b = med[0] * 8, g = med[1] * 8, r = med[2] * 8;
+    const int fX = t.cbrt_tab[(b * t.coef_fwd[0] + g * t.coef_fwd[1] + r * t.coef_fwd[2] + 2048) >> 12];
+    const int fY = t.cbrt_tab[(b * t.coef_fwd[3] + g * t.coef_fwd[4] + r * t.coef_fwd[5] + 2048) >> 12];
+    const int fZ = t.cbrt_tab[(b * t.coef_fwd[6] + g * t.coef_fwd[7] + r * t.coef_fwd[8] + 2048) >> 12];
+    const int L = (296 * fY - 1336934 + 16384) >> 15;
+    const int a = (500 * (fX - fY) + 128 * 32768 + 16384) >> 15;
+    const int bb = (200 * (fY - fZ) + 128 * 32768 + 16384) >> 15;
+    const size_t q = (size_t)blockIdx.z * HW + (size_t)y * W + x;
+    lpl[q] = (uint8_t)nf_clampi(L, 0, 255);
+    abpl[2 * q] = (uint8_t)nf_clampi(a, 0, 255);
+    abpl[2 * q + 1] = (uint8_t)nf_clampi(bb, 0, 255);
+}
+
+typedef short nf_v2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ nf_v2s nf_as_v2s(uint32_t v) { return __builtin_bit_cast(nf_v2s, v); }
+
+// 8-bit non-local means (OpenCV's FastNlMeansDenoisingInvoker, restated): for every pixel the
+// weighted mean of the 31 x 31 pixels around it, the weight of a candidate being a table look-up of
+// (sum of squared differences of the 9 x 9 windows around pixel and candidate) >> shift.
+//
+// A block produces a 16 x 16 tile from the 54 x 54 source region it stages in LDS (image extended
+// with BORDER_REFLECT_101).  Every LDS element is a dword of two 16-bit lanes so that one packed
+// subtraction and one v_dot2_i32_i16 handle two squared differences:
+//   CH == 2 (the (a, b) image): lane 0 = a, lane 1 = b of one pixel; a window is 9 x 9 dwords;
+//   CH == 1 (L): lane 0 = L(y, x), lane 1 = L(y+1, x) (array V) -- a window is 9 columns of
+//     4 such pairs plus a last row taken from array Z (lane 1 = 0).
+// The pixel's own window stays in registers; the candidate windows are read from LDS.
+template <int CH>
+__global__ __launch_bounds__(256) void k_nf_nlm(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int H, int W,
+                                                const int* __restrict__ wtab, int nw, int shift) {
+    constexpr int ROWS = CH == 2 ? NF_TW : (NF_TW + 1) / 2;
+    __shared__ uint32_t sV[NF_REGION * NF_PITCH];
+    __shared__ uint32_t sZ[CH == 1 ? NF_REGION * NF_PITCH : 1];
+    __shared__ int s_w[NF_WLDS];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const size_t HW = (size_t)H * W;
+    const uint8_t* img = src + (size_t)blockIdx.z * HW * CH;
+    const int x0 = blockIdx.x * NF_TILE - NF_BORDER, y0 = blockIdx.y * NF_TILE - NF_BORDER;
+    for (int e = tid; e < NF_WLDS; e += 256) s_w[e] = e < nw ? wtab[e] : 0;
+    for (int e = tid; e < NF_REGION * NF_REGION; e += 256) {
+        const int ry = e / NF_REGION, rx = e - ry * NF_REGION;
+        const size_t q = (size_t)nf_reflect101(y0 + ry, H) * W + nf_reflect101(x0 + rx, W);
+        if (CH == 2) sV[ry * NF_PITCH + rx] = (uint32_t)img[2 * q] | ((uint32_t)img[2 * q + 1] << 16);
+        else sZ[ry * NF_PITCH + rx] = img[q];
+    }
+    __syncthreads();
+    if (CH == 1) {
+        for (int e = tid; e < NF_REGION * NF_REGION; e += 256) {
+            const int ry = e / NF_REGION, rx = e - ry * NF_REGION;
+            const uint32_t lo = sZ[ry * NF_PITCH + rx];
+            const uint32_t hi = ry + 1 < NF_REGION ? sZ[(ry + 1) * NF_PITCH + rx] : 0u;
+            sV[ry * NF_PITCH + rx] = lo | (hi << 16);
+        }
+        __syncthreads();
+    }
+    // element (r, j) of the window whose top-left corner is LDS position (py, px)
+    auto elem = [&](int py, int px, int r, int j) -> uint32_t {
+        if (CH == 2) return sV[(py + r) * NF_PITCH + px + j];
+        if (r < ROWS - 1) return sV[(py + 2 * r) * NF_PITCH + px + j];
+        return sZ[(py + 2 * r) * NF_PITCH + px + j];
+    };
+    nf_v2s T[ROWS][NF_TW];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+        for (int j = 0; j < NF_TW; ++j) T[r][j] = nf_as_v2s(elem(ty + NF_SWH, tx + NF_SWH, r, j));
+    uint32_t est0 = 0, est1 = 0, wsum = 0;
+#pragma unroll 1
+    for (int dy = 0; dy < NF_SW; ++dy) {
+#pragma unroll 1
+        for (int dx = 0; dx < NF_SW; ++dx) {
+            int dist = 0;
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+                for (int j = 0; j < NF_TW; ++j) {
+                    const nf_v2s d = T[r][j] - nf_as_v2s(elem(ty + dy, tx + dx, r, j));
+                    dist = __builtin_amdgcn_sdot2(d, d, dist, false);
+                }
+            const int a = dist >> shift;
+            const uint32_t w = (uint32_t)(a < NF_WLDS ? s_w[a] : (a < nw ? wtab[a] : 0));
+            const int cy = ty + dy + NF_TWH, cx = tx + dx + NF_TWH;
+            if (CH == 2) {
+                const uint32_t v = sV[cy * NF_PITCH + cx];
+                est0 += w * (v & 0xffffu);
+                est1 += w * (v >> 16);
+            } else {
+                est0 += w * sZ[cy * NF_PITCH + cx];
+            }
+            wsum += w;
+        }
+    }
+    const int ox = blockIdx.x * NF_TILE + tx, oy = blockIdx.y * NF_TILE + ty;
+    if (ox < W && oy < H) {
+        uint8_t* out = dst + ((size_t)blockIdx.z * HW + (size_t)oy * W + ox) * CH;
+        const uint32_t v0 = (est0 + wsum / 2) / wsum;
+        out[0] = (uint8_t)(v0 > 255u ? 255u : v0);
+        if (CH == 2) {
+            const uint32_t v1 = (est1 + wsum / 2) / wsum;
+            out[1] = (uint8_t)(v1 > 255u ? 255u : v1);
+        }
+    }
+}
+
+// OpenCV's integer Lab -> linear BGR (COLOR_Lab2LBGR, 8 bit).
+__device__ __forceinline__ int nf_ab_to_xz(int v) {
+    // C integer arithmetic: divisions truncate toward zero
+    if (v <= 3390) return v * 108 / 841 - 290;       // 290 = 16384*16/116*108/841
+    return v * v / 16384 * v / 16384;
+}
+__device__ __forceinline__ void nf_lab_to_bgr(const NfTables& t, const uint16_t* yf, int L, int a, int b, int out[3]) {
+    const int y = yf[2 * L], ify = yf[2 * L + 1];
+    const int adiv = ((5 * a * 53687 + (1 << 7)) >> 13) - 128 * 16384 / 500;
+    const int bdiv = ((b * 41943 + (1 << 4)) >> 9) - 128 * 16384 / 200 - 1;
+    const int x = nf_ab_to_xz(ify + adiv), z = nf_ab_to_xz(ify - bdiv);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        int v = (x * t.coef_inv[3 * c] + y * t.coef_inv[3 * c + 1] + z * t.coef_inv[3 * c + 2] + (1 << 13)) >> 14;
+        v = nf_clampi(v, 0, 4095);
+        out[c] = (v * 255) >> 12;
+    }
+}
+
+// Lab -> BGR of the denoised planes, then (optionally) image - sat_u8(correlate(image,
+// [[0,1,0],[1,-4,1],[0,1,0]])) with BORDER_REFLECT_101, saturating: a thread converts its pixel and
+// its four neighbours.
+__global__ __launch_bounds__(256) void k_nf_lab2bgr_sharpen(const uint8_t* __restrict__ lpl, const uint8_t* __restrict__ abpl,
+                                                            uint8_t* __restrict__ bgr, int H, int W, int sharpen, NfTables t) {
+    __shared__ uint16_t s_yf[512];
+    for (int e = threadIdx.x; e < 512; e += 256) s_yf[e] = t.yf_tab[e];
+    __syncthreads();
+    const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (x >= W || y >= H) return;
+    const size_t HW = (size_t)H * W;
+    const uint8_t* lp = lpl + (size_t)blockIdx.z * HW;
+    const uint8_t* ab = abpl + (size_t)blockIdx.z * HW * 2;
+    auto convert = [&](int yy, int xx, int out[3]) {
+        const size_t q = (size_t)yy * W + xx;
+        nf_lab_to_bgr(t, s_yf, lp[q], ab[2 * q], ab[2 * q + 1], out);
+    };
+    int c[3];
+    convert(y, x, c);
+    if (sharpen) {
+        int n0[3], n1[3], n2[3], n3[3];
+        convert(nf_reflect101(y - 1, H), x, n0);
+        convert(nf_reflect101(y + 1, H), x, n1);
+        convert(y, nf_reflect101(x - 1, W), n2);
+        convert(y, nf_reflect101(x + 1, W), n3);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int lap = nf_clampi(n0[k] + n1[k] + n2[k] + n3[k] - 4 * c[k], 0, 255);
+            c[k] = nf_clampi(c[k] - lap, 0, 255);
+        }
+    }
+    uint8_t* out = bgr + ((size_t)blockIdx.z * HW + (size_t)y * W + x) * 3;
+    out[0] = (uint8_t)c[0]; out[1] = (uint8_t)c[1]; out[2] = (uint8_t)c[2];
+}

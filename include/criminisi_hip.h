@@ -143,6 +143,18 @@ int crim_download_device(crim_t* h, int first, int count, void* d_bgr_out);
 int crim_inpaint_noalloc(int H, int W, int patch_size, int device, const void* d_bgr,
                          const void* d_mask, void* d_bgr_out, long* iters_done);
 
+/* filter_noise(image, median_ksize, nlm_h, apply_sharpening) (src/utils.py:106-138), the stage
+ * that follows the inpainter in process_image (:216-220), for `count` dense images [count][H][W][3]:
+ * cv2.medianBlur(median_ksize) (:118), cv2.fastNlMeansDenoisingColored(h=nlm_h, hColor=1,
+ * templateWindowSize=9, searchWindowSize=31) (:124-126) and, if apply_sharpening, the Laplacian
+ * sharpening of :128-136.  median_ksize is 1, 3, 5 or 7.  Host buffers, device buffers (in place
+ * allowed), or the working images of an engine after crim_run (in place, the images stay on the GPU). */
+int crim_filter_noise(int device, int count, int H, int W, const uint8_t* bgr_in, uint8_t* bgr_out,
+                      int median_ksize, float nlm_h, int apply_sharpening);
+int crim_filter_noise_device(int device, int count, int H, int W, const void* d_bgr_in, void* d_bgr_out,
+                             int median_ksize, float nlm_h, int apply_sharpening);
+int crim_filter_noise_engine(crim_t* h, int median_ksize, float nlm_h, int apply_sharpening);
+
 /* Per-iteration decisions of image `index` (parity instrument; no counterpart in the reference
  * beyond the values its loop computes at :62-74). */
 int crim_trace(crim_t* h, int index, crim_iter_rec* buf, long cap, long* n);

@@ -147,3 +147,53 @@ def test_numpy_oracle_iteration_with_real_opencv_primitives(monkeypatch):
     got_out = got.inpaint()
     assert got.trace == want.trace
     assert np.array_equal(got_out, want_out)
+
+
+# ---- the noise-filter stage (utils.py:106-138), restated in oracle/noise_filter_np.py -----------
+
+def _nf():
+    from oracle import noise_filter_np as nf
+    return nf
+
+
+@pytest.mark.parametrize("k", [3, 5, 7])
+def test_median_blur(k):
+    rng = np.random.default_rng(k)
+    img = rng.integers(0, 256, (40, 52, 3), dtype=np.uint8)
+    assert np.array_equal(cv2.medianBlur(img, k), _nf().median_blur(img, k))
+
+
+def test_linear_bgr_to_lab_and_back():
+    c = _colours()
+    lab = cv2.cvtColor(c, cv2.COLOR_LBGR2Lab)
+    assert np.array_equal(lab, _nf().lbgr2lab_u8(c))
+    # every (L, a, b) byte triple on a lattice, not only those a colour maps to
+    v = np.arange(0, 256, 5, dtype=np.uint8)
+    L, a, b = np.meshgrid(v, v, v, indexing="ij")
+    t = np.stack([L.ravel(), a.ravel(), b.ravel()], axis=1)[None]
+    assert np.array_equal(cv2.cvtColor(t, cv2.COLOR_Lab2LBGR), _nf().lab2lbgr_u8(t))
+    assert np.array_equal(cv2.cvtColor(lab, cv2.COLOR_Lab2LBGR), _nf().lab2lbgr_u8(lab))
+
+
+@pytest.mark.parametrize("h", [3, 7, 15])
+def test_fast_nl_means_one_and_two_channels(h):
+    rng = np.random.default_rng(h)
+    one = rng.integers(60, 200, (48, 40), dtype=np.uint8)
+    assert np.array_equal(cv2.fastNlMeansDenoising(one, None, h=h, templateWindowSize=9, searchWindowSize=31),
+                          _nf().fast_nl_means_u8(one, h))
+    two = rng.integers(100, 160, (40, 44, 2), dtype=np.uint8)
+    assert np.array_equal(cv2.fastNlMeansDenoising(two, None, h=1, templateWindowSize=9, searchWindowSize=31),
+                          _nf().fast_nl_means_u8(two, 1))
+
+
+def test_fast_nl_means_colored_and_the_whole_stage():
+    import crim_synth
+    img = crim_synth.xray_like(64, 72, 77, colour=True)
+    got = cv2.fastNlMeansDenoisingColored(img, None, h=7, hColor=1, templateWindowSize=9, searchWindowSize=31)
+    assert np.array_equal(got, _nf().fast_nl_means_colored(img, 7, 1))
+    # filter_noise, utils.py:106-138, call for call
+    x = cv2.medianBlur(img, 3)
+    x = cv2.fastNlMeansDenoisingColored(x, None, h=7, hColor=1, templateWindowSize=9, searchWindowSize=31)
+    lap = cv2.filter2D(x, cv2.CV_8U, np.array([[0, 1, 0], [1, -4, 1], [0, 1, 0]]))
+    x = cv2.subtract(x, lap)
+    assert np.array_equal(x, _nf().filter_noise(img, 3, 7, True))
