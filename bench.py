@@ -331,32 +331,37 @@ def config_large(capi, device, side, patch, config_index, profile_iters=1500):
 # host-I/O-inclusive throughput of the headline batch
 # --------------------------------------------------------------------------------------------
 
-def streamed_images_per_s(capi, device, imgs, masks, steps):
-    """The headline batch from and to page-locked host memory: two engines of half the batch on two
-    host threads, each looping upload -> fill -> download, so one half's transfers overlap the
-    other half's kernels."""
+def streamed_images_per_s(capi, device, imgs, masks, steps, parts=4):
+    """The headline batch from and to page-locked host memory: `parts` engines of a share of the batch
+    each, one host thread per engine looping upload -> fill -> download.  One transfer phase at a time
+    (a lock), so the shares fall out of step and a share's PCIe transfers run under the other shares'
+    kernels."""
     B = len(imgs)
-    half = B // 2
+    part = B // parts
     pin_img, pin_msk, out = (capi.pinned_empty(imgs.shape), capi.pinned_empty(masks.shape),
                              capi.pinned_empty(imgs.shape))
     pin_img[:] = imgs
     pin_msk[:] = masks
     imgs, masks = pin_img, pin_msk
-    engines = [capi.Engine(H, W, PATCH, batch=half, device=device, flags=capi.FLAG_NO_TRACE) for _ in range(2)]
+    engines = [capi.Engine(H, W, PATCH, batch=part, device=device, flags=capi.FLAG_NO_TRACE | capi.FLAG_ONE_LANE)
+               for _ in range(parts)]
     errors = []
+    link = threading.Lock()
 
     def loop(k, n):
-        lo = k * half
+        lo = k * part
         try:
             for _ in range(n):
-                engines[k].upload(imgs[lo:lo + half], masks[lo:lo + half])
+                with link:
+                    engines[k].upload(imgs[lo:lo + part], masks[lo:lo + part])
                 engines[k].run()
-                engines[k].download(out=out[lo:lo + half])
+                with link:
+                    engines[k].download(out=out[lo:lo + part])
         except Exception as e:            # noqa: BLE001 (reported to the main thread)
             errors.append(e)
 
     def timed(n):
-        ts = [threading.Thread(target=loop, args=(k, n)) for k in range(2)]
+        ts = [threading.Thread(target=loop, args=(k, n)) for k in range(parts)]
         t0 = time.perf_counter()
         for t in ts:
             t.start()
@@ -375,7 +380,7 @@ def streamed_images_per_s(capi, device, imgs, masks, steps):
     result = out[:64].copy()
     for a in (imgs, masks, out):
         capi.pinned_free(a)
-    return 2 * half * steps / dt, result
+    return parts * part * steps / dt, result
 
 
 def main():
@@ -547,8 +552,8 @@ def main():
         v, streamed_out = streamed_images_per_s(capi, local_rank, imgs, masks, args.steps)
         result["value_incl_host_io"] = v
         result["host_io_note"] = ("same batch from and to page-locked host memory (H2D 262144 B + D2H 196608 B per "
-                                  "image over PCIe): two engines of %d images on two host threads, upload -> fill -> "
-                                  "download each, %d passes" % (B // 2, args.steps))
+                                  "image over PCIe): four engines of %d images on four host threads, upload -> fill -> "
+                                  "download each, one transfer phase at a time, %d passes" % (B // 4, args.steps))
         if gpu_first is not None:
             result["host_io_outputs_identical"] = bool(np.array_equal(streamed_out[:len(gpu_first)], gpu_first))
         del streamed_out

@@ -26,6 +26,7 @@ FLAG_GENERIC_SEARCH = 4
 FLAG_DOT4_SEARCH = 8
 FLAG_PROFILE_SOLO = 16
 FLAG_NO_TRACE = 32
+FLAG_ONE_LANE = 64
 
 MAX_PATCH = 31
 

@@ -489,6 +489,7 @@ extern "C" int crim_create_batch(int batch, int H, int W, int patch_size, int de
         // two hardware queues and every lane adds its own latency-bound launches).
         int nl = batch >= 32 ? 2 : 1;
         if (const char* env = getenv("CRIM_LANES")) nl = atoi(env);
+        if (flags & CRIM_FLAG_ONE_LANE) nl = 1;
         nl = std::max(1, std::min(nl, std::min(batch, 16)));
         h->lanes.resize(nl);
         for (int i = 0; i < nl; ++i) {

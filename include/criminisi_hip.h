@@ -58,8 +58,10 @@ enum {
                                       matrix-core one (patch sizes 3..16) */
     CRIM_FLAG_PROFILE_SOLO = 16u,  /* as CRIM_FLAG_PROFILE, but every bracketed search launch has the
                                       GPU to itself (the stream is drained after each iteration) */
-    CRIM_FLAG_NO_TRACE = 32u       /* keep no per-iteration records (crim_trace then returns none):
+    CRIM_FLAG_NO_TRACE = 32u,      /* keep no per-iteration records (crim_trace then returns none):
                                       saves 32 bytes per image and possible iteration */
+    CRIM_FLAG_ONE_LANE = 64u       /* the whole batch advances on one stream (for a caller that runs
+                                      several engines side by side, e.g. to overlap their transfers) */
 };
 
 /* Largest patch_size accepted.  The reference takes any integer (:18); the bit-exact regime
