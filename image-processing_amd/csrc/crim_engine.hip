@@ -216,7 +216,12 @@ static void free_graphs(crim_engine* h) {
 }
 
 // Search over block rows [sy0, sy0 + rows) of the window-origin grid (all rows when rows < 0).
-static void launch_search(const Params& pin, hipStream_t s, int sy0 = 0, int rows = -1) {
+// Does the search launch also do the select stage's work?  (only the pipelined matrix-core kernel can)
+static bool search_selects(const Params& p) {
+    return p.selsearch && !p.generic && !p.dot4 && p.pipe_t > 0 && p.P >= 3 && p.P <= 15 && (p.P & 1);
+}
+
+static void launch_search(const Params& pin, hipStream_t s, int sy0 = 0, int rows = -1, bool sel = false) {
     Params p = pin;
     p.sy0 = sy0;
     if (rows < 0) rows = p.sny;
@@ -241,13 +246,13 @@ static void launch_search(const Params& pin, hipStream_t s, int sy0 = 0, int row
             p.mchunks = (rows + T - 1) / T;
             dim3 pgrid((unsigned)p.mgx * p.mchunks * p.B);
             switch (p.P) {
-                case 3: if (p.chroma) hipLaunchKernelGGL((k_search_pipe<3, true>), pgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_pipe<3, false>), pgrid, block, 0, s, p); return;
-                case 5: if (p.chroma) hipLaunchKernelGGL((k_search_pipe<5, true>), pgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_pipe<5, false>), pgrid, block, 0, s, p); return;
-                case 7: if (p.chroma) hipLaunchKernelGGL((k_search_pipe<7, true>), pgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_pipe<7, false>), pgrid, block, 0, s, p); return;
-                case 9: if (p.chroma) hipLaunchKernelGGL((k_search_pipe<9, true>), pgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_pipe<9, false>), pgrid, block, 0, s, p); return;
-                case 11: if (p.chroma) hipLaunchKernelGGL((k_search_pipe<11, true>), pgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_pipe<11, false>), pgrid, block, 0, s, p); return;
-                case 13: if (p.chroma) hipLaunchKernelGGL((k_search_pipe<13, true>), pgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_pipe<13, false>), pgrid, block, 0, s, p); return;
-                case 15: if (p.chroma) hipLaunchKernelGGL((k_search_pipe<15, true>), pgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_pipe<15, false>), pgrid, block, 0, s, p); return;
+                case 3: if (p.chroma) { if (sel) hipLaunchKernelGGL((k_search_pipe<3, true, true>), pgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_pipe<3, true, false>), pgrid, block, 0, s, p); } else { if (sel) hipLaunchKernelGGL((k_search_pipe<3, false, true>), pgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_pipe<3, false, false>), pgrid, block, 0, s, p); } return;
+                case 5: if (p.chroma) { if (sel) hipLaunchKernelGGL((k_search_pipe<5, true, true>), pgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_pipe<5, true, false>), pgrid, block, 0, s, p); } else { if (sel) hipLaunchKernelGGL((k_search_pipe<5, false, true>), pgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_pipe<5, false, false>), pgrid, block, 0, s, p); } return;
+                case 7: if (p.chroma) { if (sel) hipLaunchKernelGGL((k_search_pipe<7, true, true>), pgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_pipe<7, true, false>), pgrid, block, 0, s, p); } else { if (sel) hipLaunchKernelGGL((k_search_pipe<7, false, true>), pgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_pipe<7, false, false>), pgrid, block, 0, s, p); } return;
+                case 9: if (p.chroma) { if (sel) hipLaunchKernelGGL((k_search_pipe<9, true, true>), pgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_pipe<9, true, false>), pgrid, block, 0, s, p); } else { if (sel) hipLaunchKernelGGL((k_search_pipe<9, false, true>), pgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_pipe<9, false, false>), pgrid, block, 0, s, p); } return;
+                case 11: if (p.chroma) { if (sel) hipLaunchKernelGGL((k_search_pipe<11, true, true>), pgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_pipe<11, true, false>), pgrid, block, 0, s, p); } else { if (sel) hipLaunchKernelGGL((k_search_pipe<11, false, true>), pgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_pipe<11, false, false>), pgrid, block, 0, s, p); } return;
+                case 13: if (p.chroma) { if (sel) hipLaunchKernelGGL((k_search_pipe<13, true, true>), pgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_pipe<13, true, false>), pgrid, block, 0, s, p); } else { if (sel) hipLaunchKernelGGL((k_search_pipe<13, false, true>), pgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_pipe<13, false, false>), pgrid, block, 0, s, p); } return;
+                case 15: if (p.chroma) { if (sel) hipLaunchKernelGGL((k_search_pipe<15, true, true>), pgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_pipe<15, true, false>), pgrid, block, 0, s, p); } else { if (sel) hipLaunchKernelGGL((k_search_pipe<15, false, true>), pgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_pipe<15, false, false>), pgrid, block, 0, s, p); } return;
                 default: break;
             }
         }
@@ -316,9 +321,10 @@ static int compact_period(const Params& p) { return p.tnx * p.tny > 1024 ? 64 : 
 static void launch_iteration(const Params& p, hipStream_t s, hipEvent_t ev0 = nullptr,
                              hipEvent_t ev1 = nullptr) {
     launch_priority(p, s);
-    hipLaunchKernelGGL(k_select, dim3(p.B), dim3(256), 0, s, p);
+    const bool sel = search_selects(p);
+    if (!sel) hipLaunchKernelGGL(k_select, dim3(p.B), dim3(256), 0, s, p);
     if (ev0) (void)hipEventRecord(ev0, s);
-    launch_search(p, s);
+    launch_search(p, s, 0, -1, sel);
     if (ev1) (void)hipEventRecord(ev1, s);
     launch_update(p, s);
 }
@@ -377,6 +383,13 @@ static void init_geometry(Params& p, int batch, int H, int W, int patch_size, un
     }
     p.b0 = 0;
     p.trace_cap = 0;
+    // Small batches wait for their launch boundaries and round trips: the search launch then also picks
+    // the target and builds the template (one launch less per iteration); every search block reads the
+    // priority stage's slots, so there are fewer of them.
+    p.selsearch = batch < 32 ? 1 : 0;
+    if (const char* e = getenv("CRIM_SELECT_IN_SEARCH")) p.selsearch = atoi(e) ? 1 : 0;
+    if (flags & (CRIM_FLAG_PROFILE | CRIM_FLAG_PROFILE_SOLO)) p.selsearch = 0;   // the bracketed launch is the search alone
+    if (p.selsearch && !getenv("CRIM_PGRID")) p.pgrid = std::min(p.pgrid, 1024);
 }
 
 extern "C" int crim_device_count(void) {

@@ -1079,14 +1079,18 @@ __global__ __launch_bounds__(256) void k_select(Params p) {
 // Does the ph x pw window at origin (y, x) avoid every masked pixel (:250-255)?  The cached
 // map answers for full P x P windows; smaller (border-clipped) windows are contained in the
 // full window when that fits, and are scanned otherwise.
-__device__ __forceinline__ bool window_valid(const Params& p, const Desc* d, const uint8_t* inv,
-                                             const uint8_t* mask, int y, int x) {
+__device__ __forceinline__ bool window_valid_geom(const Params& p, int clipped, int ph, int pw, const uint8_t* inv,
+                                                  const uint8_t* mask, int y, int x) {
     if (y <= p.H - p.P && x <= p.W - p.P && inv[(size_t)y * p.Wi + x] == 0) return true;
-    if (!d->clipped) return false;
-    for (int i = 0; i < d->ph; ++i)
-        for (int j = 0; j < d->pw; ++j)
+    if (!clipped) return false;
+    for (int i = 0; i < ph; ++i)
+        for (int j = 0; j < pw; ++j)
             if (mask[(size_t)(y + i) * p.W + x + j]) return false;
     return true;
+}
+__device__ __forceinline__ bool window_valid(const Params& p, const Desc* d, const uint8_t* inv,
+                                             const uint8_t* mask, int y, int x) {
+    return window_valid_geom(p, d->clipped, d->ph, d->pw, inv, mask, y, x);
 }
 
 __device__ __forceinline__ bool better_cost(double ca, unsigned ia, double cb, unsigned ib) {
@@ -1708,7 +1712,12 @@ __device__ __forceinline__ void publish_barrier() {
 #define MSP_WPE(P, CHROMA) (((P) > 9 || ((CHROMA) && (P) > 7)) ? 3 : 4)
 #endif
 
-template <int P, bool CHROMA>
+// SELECT: the launch also does the work of k_select.  Every block picks the target itself from the
+// priority stage's per-wave slots and builds the template rows straight into its LDS (the first
+// block of the image also writes the descriptor for k_update): one launch and one round trip less
+// per iteration, which is what small batches -- above all a single large image -- wait for.  The
+// tile loads are requested between the two steps, so they travel with the target patch's pixels.
+template <int P, bool CHROMA, bool SELECT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MSP_WPE(P, CHROMA), MSP_WPE(P, CHROMA))))
 void k_search_pipe(Params p) {
     constexpr int NCC = CHROMA ? 3 : 1;         // cross-term channels
@@ -1737,32 +1746,100 @@ void k_search_pipe(Params p) {
     int img_, sub_;
     xcd_decode(blockIdx.x, p.mgx * p.mchunks, p.B, &img_, &sub_);
     const int b = p.b0 + img_;
-    const Desc* __restrict__ d = p.desc + b;
-    if (!d->live) return;
-    const int ncy = d->ncy, ncx = d->ncx;
+    Desc* __restrict__ d = p.desc + b;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int H = p.H, W = p.W, Wp = p.Wp;
+    const size_t HW = (size_t)H * W;
+    const uint8_t* mask = p.mask + b * HW;
     const int chunk = sub_ / p.mgx, tbx = sub_ - chunk * p.mgx;
     const int tb0 = p.sy0 + chunk * p.mtiles;          // first row of tiles of this block
     const int x0 = tbx * MS_W;
+    // target geometry and what the pricing needs: from the descriptor, or (SELECT) worked out here
+    int ncy, ncx, clipped, chmask, soff, r0s = 0, c0s = 0, phs = 0, pws = 0;
+    double ph_half, pw_half, ty, tx;
+    // SELECT: k*T and k of the target patch, flattened row-major with row length P
+    __shared__ uint8_t s_sk[SELECT ? P * P : 1];
+    __shared__ int8_t s_st[SELECT ? 3 : 1][SELECT ? P * P : 1];
+    __shared__ double s_sp[4];
+    __shared__ int s_si[4];
+    __shared__ int s_red[4];   // soff, nk, rowmask, chmask
+    if constexpr (!SELECT) {
+        if (!d->live) return;
+        ncy = d->ncy; ncx = d->ncx;
+        clipped = d->clipped;
+        chmask = d->chmask & (CHROMA ? 7 : 1);
+        soff = d->soff2;
+        ph_half = (double)d->ph / 2.0; pw_half = (double)d->pw / 2.0;
+        ty = d->ty; tx = d->tx;
+        phs = d->ph; pws = d->pw;
+    } else {
+        // ---- step 1 of k_select: arg-max over the priority stage's slots (highest priority, lowest
+        // row-major index; an empty front leaves the target at pixel 0, :216-218)
+        const ImgState* st = p.st + b;
+        const PEntry* pl_ = p.plist + (size_t)b * p.pgrid;
+        constexpr int NSPEC = 4;
+        PEntry spec[NSPEC];
+#pragma unroll
+        for (int k = 0; k < NSPEC; ++k) spec[k] = pl_[imin(tid + 256 * k, p.pgrid - 1)];
+        const int live = st->live;
+        const int cur = st->cur;
+        if (!live) {
+            if (sub_ == 0 && tid == 0) d->live = 0;
+            return;
+        }
+        double bestP = -1.0;
+        int bestI = 0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < NSPEC; ++k)
+            if (tid + 256 * k < p.pgrid && better_prio(spec[k].prio, spec[k].pos, bestP, bestI)) {
+                bestP = spec[k].prio; bestI = spec[k].pos;
+            }
+        for (int i = tid + 256 * NSPEC; i < p.pgrid; i += 256) {
+            const PEntry e = pl_[i];
+            if (better_prio(e.prio, e.pos, bestP, bestI)) { bestP = e.prio; bestI = e.pos; }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const double op = __shfl_down(bestP, off);
+            const int oi = __shfl_down(bestI, off);
+            if (better_prio(op, oi, bestP, bestI)) { bestP = op; bestI = oi; }
+        }
+        if (lane == 0) { s_sp[wv] = bestP; s_si[wv] = bestI; }
+        if (tid < 4) s_red[tid] = 0;
+        __syncthreads();
+        bestP = s_sp[0]; bestI = s_si[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (better_prio(s_sp[w], s_si[w], bestP, bestI)) { bestP = s_sp[w]; bestI = s_si[w]; }
+        const int pos = bestP > 0.0 ? bestI : 0;
+        const int tr = pos / W, tc = pos - tr * W;
+        const int r1 = imin(tr + p.half, H - 1), c1 = imin(tc + p.half, W - 1);
+        r0s = imax(0, tr - p.half); c0s = imax(0, tc - p.half);
+        phs = r1 - r0s + 1; pws = c1 - c0s + 1;
+        clipped = (phs != P || pws != P) ? 1 : 0;
+        ncy = H - phs + 1; ncx = W - pws + 1;
+        ph_half = (double)phs / 2.0; pw_half = (double)pws / 2.0;
+        ty = (double)(r0s + r1) / 2.0; tx = (double)(c0s + c1) / 2.0;
+        if (sub_ == 0 && tid == 0) {
+            // what k_update reads
+            d->live = 1;
+            d->tr = tr; d->tc = tc; d->r0 = r0s; d->c0 = c0s; d->ph = phs; d->pw = pws;
+            d->clipped = clipped;
+            d->ncy = ncy; d->ncx = ncx;
+            d->ty = ty; d->tx = tx;
+            d->cnew = p.conf[((size_t)b * 2 + (cur ^ 1)) * HW + pos];
+        }
+        soff = 0; chmask = 0;   // set after step 2
+    }
     if (x0 >= ncx) return;
     int T = imin(p.mtiles, p.mrows - chunk * p.mtiles);
     T = imin(T, (ncy - tb0 * MS_ROWS + MS_ROWS - 1) / MS_ROWS);
     if (T <= 0) return;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int H = p.H, W = p.W, Wp = p.Wp;
-    const size_t HW = (size_t)H * W;
-    // everything the pricing needs from the descriptor, read before the first barrier
-    const int clipped = d->clipped;
-    const int chmask = d->chmask & (CHROMA ? 7 : 1);
-    const int soff = d->soff2;
-    const double ph_half = (double)d->ph / 2.0, pw_half = (double)d->pw / 2.0;
-    const double ty = d->ty, tx = d->tx;
     int bound0 = 0;
     if (tid == 0) {
         bound0 = __hip_atomic_load(&p.st[b].bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_bound = bound0;
     }
     const uint8_t* inv = p.invalid + (size_t)b * H * p.Wi;
-    const uint8_t* mask = p.mask + b * HW;
     const int wx = x0 + 64 * (lane >> 4) + (lane & 15);
 
     // ---- ring loads.  Chunk c = tid + 256 k of a tile is row c / C16, bytes 16 (c % C16) ..;
@@ -1808,13 +1885,74 @@ void k_search_pipe(Params p) {
     load_plane(plane_of(2), coff, 2);
     constexpr int NZ = (NCC + 1) * 2 * NS;
     static_assert(NZ <= 256, "one template row per thread");
-    if (tid < NZ) {
-        const int row = tid % (2 * NS), type = tid / (2 * NS);
-        uint4 zv = make_uint4(0, 0, 0, 0);
-        if (row < P && (type == NCC || ((chmask >> type) & 1)))
-            zv = *(const uint4*)d->zrows[type == NCC ? 3 : type][row];
-        uint4* z = (uint4*)&zl[0][0][0] + 3 * tid;
-        z[0] = make_uint4(0, 0, 0, 0); z[1] = zv; z[2] = make_uint4(0, 0, 0, 0);
+    if constexpr (!SELECT) {
+        if (tid < NZ) {
+            const int row = tid % (2 * NS), type = tid / (2 * NS);
+            uint4 zv = make_uint4(0, 0, 0, 0);
+            if (row < P && (type == NCC || ((chmask >> type) & 1)))
+                zv = *(const uint4*)d->zrows[type == NCC ? 3 : type][row];
+            uint4* z = (uint4*)&zl[0][0][0] + 3 * tid;
+            z[0] = make_uint4(0, 0, 0, 0); z[1] = zv; z[2] = make_uint4(0, 0, 0, 0);
+        }
+    } else {
+        // ---- step 2 of k_select: k = 1 - mask and k * (Lab - 128) over the target patch (:227-235),
+        // read while the tile loads above travel
+        static_assert(P * P <= 256, "one patch element per thread");
+        {
+            const int e = imin(tid, P * P - 1);
+            const int i = e / P, j = e - i * P;
+            const int yy = imin(r0s + i, H - 1), xx = imin(c0s + j, W - 1);
+            const int em = mask[(size_t)yy * W + xx];
+            const size_t o = (size_t)yy * Wp + xx;
+            const int e0 = (int8_t)pl[o], e1 = (int8_t)pl[plane_bytes + o], e2 = (int8_t)pl[2 * plane_bytes + o];
+            int soff_l = 0, nk_l = 0, rowm_l = 0, chm_l = 0;
+            if (tid < P * P) {
+                int k = 0, t0 = 0, t1 = 0, t2 = 0;
+                if (i < phs && j < pws && !em) {
+                    k = 1;
+                    t0 = e0; t1 = e1; t2 = e2;
+                    soff_l = -256 * (t0 + t1 + t2) - 3 * 16384;   // sum k*T~^2 - sum k*T^2 with T = T~ + 128
+                    nk_l = 1;
+                    rowm_l = 1 << i;
+                    chm_l = (t0 ? 1 : 0) | (t1 ? 2 : 0) | (t2 ? 4 : 0);
+                }
+                s_sk[tid] = (uint8_t)k;
+                s_st[0][tid] = (int8_t)t0; s_st[1][tid] = (int8_t)t1; s_st[2][tid] = (int8_t)t2;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                soff_l += __shfl_xor(soff_l, off);
+                nk_l += __shfl_xor(nk_l, off);
+                rowm_l |= __shfl_xor(rowm_l, off);
+                chm_l |= __shfl_xor(chm_l, off);
+            }
+            if (lane == 0 && nk_l) {
+                atomicAdd(&s_red[0], soff_l);
+                atomicAdd(&s_red[1], nk_l);
+                atomicOr(&s_red[2], rowm_l);
+                atomicOr(&s_red[3], chm_l);
+            }
+        }
+        publish_barrier<63>();                 // LDS only: the tile loads stay in flight
+        soff = s_red[0] + 24576 * s_red[1];
+        chmask = s_red[3] & (CHROMA ? 7 : 1);
+        if (tid < NZ) {
+            const int row = tid % (2 * NS), type = tid / (2 * NS);
+            unsigned long long lo = 0, hi = 0;
+            if (row < P && (type == NCC || ((chmask >> type) & 1))) {
+                const uint8_t* src = type == NCC ? &s_sk[row * P] : (const uint8_t*)&s_st[type][row * P];
+#pragma unroll
+                for (int c = 0; c < P; ++c) {
+                    const unsigned long long byte = src[c];
+                    if (c < 8) lo |= byte << (8 * c);
+                    else hi |= byte << (8 * (c - 8));
+                }
+            }
+            uint4 zv;
+            zv.x = (uint32_t)lo; zv.y = (uint32_t)(lo >> 32); zv.z = (uint32_t)hi; zv.w = (uint32_t)(hi >> 32);
+            uint4* z = (uint4*)&zl[0][0][0] + 3 * tid;
+            z[0] = make_uint4(0, 0, 0, 0); z[1] = zv; z[2] = make_uint4(0, 0, 0, 0);
+        }
     }
 
     const int g = lane >> 4;
@@ -1931,7 +2069,7 @@ void k_search_pipe(Params p) {
                     for (int yy = 0; yy < R; ++yy)
                         for (int jj = 0; jj < 4; ++jj) {
                             const int y = wy + yy, x = wx + 16 * jj;
-                            const int ok = (y < ncy && x < ncx && window_valid(p, d, inv, mask, y, x)) ? 1 : 0;
+                            const int ok = (y < ncy && x < ncx && window_valid_geom(p, clipped, phs, pws, inv, mask, y, x)) ? 1 : 0;
                             acc[yy][jj] = ok ? 0 : -POISON;
                             anyvalid |= ok;
                         }
@@ -2496,6 +2634,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PM <= 9 ? 8
         st->remaining = rem;
         st->iter = it + 1;
         st->cur = cur ^ 1;
+        st->bound = 0x7fffffff;   // the next search starts without a pruning bound
         if (rem <= 0) st->live = 0;
         else if (nf == 0) { st->live = 0; st->stalled = 1; }
     }
