@@ -1090,7 +1090,12 @@ __device__ __forceinline__ bool window_valid_geom(const Params& p, int clipped, 
 }
 __device__ __forceinline__ bool window_valid(const Params& p, const Desc* d, const uint8_t* inv,
                                              const uint8_t* mask, int y, int x) {
-    return window_valid_geom(p, d->clipped, d->ph, d->pw, inv, mask, y, x);
+    if (y <= p.H - p.P && x <= p.W - p.P && inv[(size_t)y * p.Wi + x] == 0) return true;
+    if (!d->clipped) return false;
+    for (int i = 0; i < d->ph; ++i)
+        for (int j = 0; j < d->pw; ++j)
+            if (mask[(size_t)(y + i) * p.W + x + j]) return false;
+    return true;
 }
 
 __device__ __forceinline__ bool better_cost(double ca, unsigned ia, double cb, unsigned ib) {
@@ -1717,8 +1722,10 @@ __device__ __forceinline__ void publish_barrier() {
 // block of the image also writes the descriptor for k_update): one launch and one round trip less
 // per iteration, which is what small batches -- above all a single large image -- wait for.  The
 // tile loads are requested between the two steps, so they travel with the target patch's pixels.
+// (SELECT instances serve small batches, which never fill four blocks per CU: three waves per SIMD
+// give them the registers the extra prologue needs)
 template <int P, bool CHROMA, bool SELECT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MSP_WPE(P, CHROMA), MSP_WPE(P, CHROMA))))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SELECT ? 3 : MSP_WPE(P, CHROMA), SELECT ? 3 : MSP_WPE(P, CHROMA))))
 void k_search_pipe(Params p) {
     constexpr int NCC = CHROMA ? 3 : 1;         // cross-term channels
     constexpr int NP = NCC + 2;                 // planes (passes) per tile
@@ -1746,35 +1753,22 @@ void k_search_pipe(Params p) {
     int img_, sub_;
     xcd_decode(blockIdx.x, p.mgx * p.mchunks, p.B, &img_, &sub_);
     const int b = p.b0 + img_;
-    Desc* __restrict__ d = p.desc + b;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int H = p.H, W = p.W, Wp = p.Wp;
-    const size_t HW = (size_t)H * W;
-    const uint8_t* mask = p.mask + b * HW;
-    const int chunk = sub_ / p.mgx, tbx = sub_ - chunk * p.mgx;
-    const int tb0 = p.sy0 + chunk * p.mtiles;          // first row of tiles of this block
-    const int x0 = tbx * MS_W;
-    // target geometry and what the pricing needs: from the descriptor, or (SELECT) worked out here
-    int ncy, ncx, clipped, chmask, soff, r0s = 0, c0s = 0, phs = 0, pws = 0;
-    double ph_half, pw_half, ty, tx;
+    const Desc* __restrict__ d = p.desc + b;
     // SELECT: k*T and k of the target patch, flattened row-major with row length P
     __shared__ uint8_t s_sk[SELECT ? P * P : 1];
     __shared__ int8_t s_st[SELECT ? 3 : 1][SELECT ? P * P : 1];
-    __shared__ double s_sp[4];
-    __shared__ int s_si[4];
-    __shared__ int s_red[4];   // soff, nk, rowmask, chmask
+    __shared__ double s_sp[SELECT ? 4 : 1];
+    __shared__ int s_si[SELECT ? 4 : 1];
+    __shared__ int s_red[7];   // soff, nk, rowmask, chmask; SELECT: ph, pw of the target patch (read by the rare clipped path)
+    // target geometry worked out by this block (SELECT only)
+    struct { int ncy, ncx, clipped, r0, c0, ph, pw; double ty, tx; } sel = {};
     if constexpr (!SELECT) {
         if (!d->live) return;
-        ncy = d->ncy; ncx = d->ncx;
-        clipped = d->clipped;
-        chmask = d->chmask & (CHROMA ? 7 : 1);
-        soff = d->soff2;
-        ph_half = (double)d->ph / 2.0; pw_half = (double)d->pw / 2.0;
-        ty = d->ty; tx = d->tx;
-        phs = d->ph; pws = d->pw;
     } else {
         // ---- step 1 of k_select: arg-max over the priority stage's slots (highest priority, lowest
         // row-major index; an empty front leaves the target at pixel 0, :216-218)
+        const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+        const int H = p.H, W = p.W;
         const ImgState* st = p.st + b;
         const PEntry* pl_ = p.plist + (size_t)b * p.pgrid;
         constexpr int NSPEC = 4;
@@ -1783,8 +1777,9 @@ void k_search_pipe(Params p) {
         for (int k = 0; k < NSPEC; ++k) spec[k] = pl_[imin(tid + 256 * k, p.pgrid - 1)];
         const int live = st->live;
         const int cur = st->cur;
+        Desc* dw = p.desc + b;   // the first block of the image writes what k_update reads
         if (!live) {
-            if (sub_ == 0 && tid == 0) d->live = 0;
+            if (sub_ == 0 && tid == 0) dw->live = 0;
             return;
         }
         double bestP = -1.0;
@@ -1813,33 +1808,45 @@ void k_search_pipe(Params p) {
         const int pos = bestP > 0.0 ? bestI : 0;
         const int tr = pos / W, tc = pos - tr * W;
         const int r1 = imin(tr + p.half, H - 1), c1 = imin(tc + p.half, W - 1);
-        r0s = imax(0, tr - p.half); c0s = imax(0, tc - p.half);
-        phs = r1 - r0s + 1; pws = c1 - c0s + 1;
-        clipped = (phs != P || pws != P) ? 1 : 0;
-        ncy = H - phs + 1; ncx = W - pws + 1;
-        ph_half = (double)phs / 2.0; pw_half = (double)pws / 2.0;
-        ty = (double)(r0s + r1) / 2.0; tx = (double)(c0s + c1) / 2.0;
+        sel.r0 = imax(0, tr - p.half); sel.c0 = imax(0, tc - p.half);
+        sel.ph = r1 - sel.r0 + 1; sel.pw = c1 - sel.c0 + 1;
+        sel.clipped = (sel.ph != P || sel.pw != P) ? 1 : 0;
+        sel.ncy = H - sel.ph + 1; sel.ncx = W - sel.pw + 1;
+        sel.ty = (double)(sel.r0 + r1) / 2.0; sel.tx = (double)(sel.c0 + c1) / 2.0;
+        if (tid == 0) { s_red[4] = sel.ph; s_red[5] = sel.pw; }
         if (sub_ == 0 && tid == 0) {
-            // what k_update reads
-            d->live = 1;
-            d->tr = tr; d->tc = tc; d->r0 = r0s; d->c0 = c0s; d->ph = phs; d->pw = pws;
-            d->clipped = clipped;
-            d->ncy = ncy; d->ncx = ncx;
-            d->ty = ty; d->tx = tx;
-            d->cnew = p.conf[((size_t)b * 2 + (cur ^ 1)) * HW + pos];
+            dw->live = 1;
+            dw->tr = tr; dw->tc = tc; dw->r0 = sel.r0; dw->c0 = sel.c0; dw->ph = sel.ph; dw->pw = sel.pw;
+            dw->clipped = sel.clipped;
+            dw->ncy = sel.ncy; dw->ncx = sel.ncx;
+            dw->ty = sel.ty; dw->tx = sel.tx;
+            dw->cnew = p.conf[((size_t)b * 2 + (cur ^ 1)) * ((size_t)H * W) + pos];
         }
-        soff = 0; chmask = 0;   // set after step 2
     }
+    const int ncy = SELECT ? sel.ncy : d->ncy, ncx = SELECT ? sel.ncx : d->ncx;
+    const int chunk = sub_ / p.mgx, tbx = sub_ - chunk * p.mgx;
+    const int tb0 = p.sy0 + chunk * p.mtiles;          // first row of tiles of this block
+    const int x0 = tbx * MS_W;
     if (x0 >= ncx) return;
     int T = imin(p.mtiles, p.mrows - chunk * p.mtiles);
     T = imin(T, (ncy - tb0 * MS_ROWS + MS_ROWS - 1) / MS_ROWS);
     if (T <= 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int H = p.H, W = p.W, Wp = p.Wp;
+    const size_t HW = (size_t)H * W;
+    // everything the pricing needs from the descriptor, read before the first barrier
+    const int clipped = SELECT ? sel.clipped : d->clipped;
+    int chmask = SELECT ? 0 : (d->chmask & (CHROMA ? 7 : 1));       // SELECT: set with the template rows below
+    int soff = SELECT ? 0 : d->soff2;
+    const double ph_half = (double)(SELECT ? sel.ph : d->ph) / 2.0, pw_half = (double)(SELECT ? sel.pw : d->pw) / 2.0;
+    const double ty = SELECT ? sel.ty : d->ty, tx = SELECT ? sel.tx : d->tx;
     int bound0 = 0;
     if (tid == 0) {
         bound0 = __hip_atomic_load(&p.st[b].bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_bound = bound0;
     }
     const uint8_t* inv = p.invalid + (size_t)b * H * p.Wi;
+    const uint8_t* mask = p.mask + b * HW;
     const int wx = x0 + 64 * (lane >> 4) + (lane & 15);
 
     // ---- ring loads.  Chunk c = tid + 256 k of a tile is row c / C16, bytes 16 (c % C16) ..;
@@ -1901,14 +1908,14 @@ void k_search_pipe(Params p) {
         {
             const int e = imin(tid, P * P - 1);
             const int i = e / P, j = e - i * P;
-            const int yy = imin(r0s + i, H - 1), xx = imin(c0s + j, W - 1);
+            const int yy = imin(sel.r0 + i, H - 1), xx = imin(sel.c0 + j, W - 1);
             const int em = mask[(size_t)yy * W + xx];
             const size_t o = (size_t)yy * Wp + xx;
             const int e0 = (int8_t)pl[o], e1 = (int8_t)pl[plane_bytes + o], e2 = (int8_t)pl[2 * plane_bytes + o];
             int soff_l = 0, nk_l = 0, rowm_l = 0, chm_l = 0;
             if (tid < P * P) {
                 int k = 0, t0 = 0, t1 = 0, t2 = 0;
-                if (i < phs && j < pws && !em) {
+                if (i < sel.ph && j < sel.pw && !em) {
                     k = 1;
                     t0 = e0; t1 = e1; t2 = e2;
                     soff_l = -256 * (t0 + t1 + t2) - 3 * 16384;   // sum k*T~^2 - sum k*T^2 with T = T~ + 128
@@ -2069,7 +2076,10 @@ void k_search_pipe(Params p) {
                     for (int yy = 0; yy < R; ++yy)
                         for (int jj = 0; jj < 4; ++jj) {
                             const int y = wy + yy, x = wx + 16 * jj;
-                            const int ok = (y < ncy && x < ncx && window_valid_geom(p, clipped, phs, pws, inv, mask, y, x)) ? 1 : 0;
+                            bool wok;
+                            if constexpr (SELECT) wok = window_valid_geom(p, 1, s_red[1 + 3], s_red[2 + 3], inv, mask, y, x);
+                            else wok = window_valid(p, d, inv, mask, y, x);
+                            const int ok = (y < ncy && x < ncx && wok) ? 1 : 0;
                             acc[yy][jj] = ok ? 0 : -POISON;
                             anyvalid |= ok;
                         }

@@ -104,7 +104,6 @@ struct Params {
     int generic;  // use the unspecialised search kernel
     int dot4;     // use the vector dot-product search kernel instead of the matrix-core one
     int chroma;   // some uploaded image is not grey: the matrix-core search stages all five planes
-    int selsearch; // the pipelined search also picks the target and builds the template (no k_select launch)
     long trace_cap;
     uint8_t* bgr;      // [B][H][W][3]
     uint8_t* planes;   // [B][CRIM_NPL][H][Wp]  L-128, a-128, b-128 (int8), Q%255, Q/255 (uint8),
@@ -128,4 +127,5 @@ struct Params {
     const uint16_t* gamma_tab;
     const uint16_t* cbrt_tab;
     int coef[9];
+    int selsearch;     // host side: the pipelined search also picks the target and builds the template (no k_select launch)
 };
