@@ -2283,6 +2283,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PM <= 9 ? 8
     __shared__ unsigned long long s_rw[MR][2];         // OR of P consecutive rows
     __shared__ int s_ovf;                              // the tile list outgrew its capacity
     __shared__ unsigned s_tw[4];
+    __shared__ int s_td[9];                            // change of the front count of the (up to 3 x 3) tiles around the patch
+    __shared__ unsigned s_napp;                        // tiles appended to the list by this iteration
 
     // The kernel is a chain of dependent memory round trips, so independent loads are issued
     // together.  Load batch 1: loop state, descriptor, and the partial arg-min list (read up to its
@@ -2297,6 +2299,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PM <= 9 ? 8
     // loop state is read once, up front: thread 0 rewrites it at the end of this kernel
     const int cur = st->cur;
     const int remaining0 = st->remaining, iter0 = st->iter;
+    const unsigned tcount0 = st->tcount;
     const int ncx = d->ncx;
     // entries to reduce: the exchange slots of a split search, else the slots of the search blocks
     // inside the candidate grid
@@ -2307,6 +2310,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PM <= 9 ? 8
     const int r0 = d->r0, c0 = d->c0, ph = d->ph, pw = d->pw;
     const double cnew = d->cnew;
     if (!live) return;
+    // the (up to 3 x 3) 16 x 16 tiles that pixels within one pixel of the patch lie in, and their
+    // front counts, requested early
+    const int tty0 = imax(r0 - 1, 0) / CRIM_TILE, ttx0 = imax(c0 - 1, 0) / CRIM_TILE;
+    int tf_old = 0;
+    if (tid < 9) {
+        const int ti = imin(tty0 + tid / 3, p.tny - 1), tj = imin(ttx0 + tid % 3, p.tnx - 1);
+        tf_old = p.tfront[(size_t)b * p.tnx * p.tny + ti * p.tnx + tj];
+    }
     STAMP(16);
     uint8_t* mask = p.mask + b * HW;
     uint8_t* bgr = p.bgr + b * HW * 3;
@@ -2408,7 +2419,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PM <= 9 ? 8
         if (better_cost(oc, oi, bc, bi)) { bc = oc; bi = oi; }
     }
     if ((tid & 63) == 0) { s_c[tid >> 6] = bc; s_i[tid >> 6] = bi; }
-    if (tid == 0) { s_filled = 0; s_ovf = 0; }
+    if (tid == 0) { s_filled = 0; s_ovf = 0; s_napp = 0u; }
+    if (tid < 9) s_td[tid] = 0;
     if (tid < (PM * PM + 31) / 32) s_fill[tid] = 0;
     __syncthreads();
     if (tid == 0) {
@@ -2534,8 +2546,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PM <= 9 ? 8
         auto MO = [&](int y2, int x2) -> int {
             return (int)s_m0[(reflect101(y2, H) - mr0) * MR + (reflect101(x2, W) - mc0)];
         };
-        int* tf = p.tfront + (size_t)b * p.tnx * p.tny;
-        int* tl = p.tlist + (size_t)b * p.tcap;
+        // Only this block changes its image's counts, so they need no global atomics: the changes are
+        // summed per tile in LDS, and one thread per tile applies them to the count it requested with
+        // the first batch of loads.  A tile enters the list when its count leaves zero.
         const int fh = ph + 2, fw = pw + 2;
         for (int e = tid; e < fh * fw; e += 256) {
             const int i = e / fw, j = e - i * fw;
@@ -2546,15 +2559,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PM <= 9 ? 8
             const bool fn = MN(yy, xx) == 0 &&
                             MN(yy - 1, xx - 1) + MN(yy - 1, xx + 1) + MN(yy + 1, xx - 1) + MN(yy + 1, xx + 1) > 0;
             if (fo == fn) continue;
-            const int tile = (yy / CRIM_TILE) * p.tnx + xx / CRIM_TILE;
-            if (fn) {
-                if (atomicAdd(&tf[tile], 1) == 0) {
-                    const unsigned k = atomicAdd(&st->tcount, 1u);
-                    if (k < (unsigned)p.tcap) tl[k] = tile;
-                    else s_ovf = 1;   // dropped: the list is rebuilt from the counts below
-                }
-            } else {
-                atomicSub(&tf[tile], 1);
+            atomicAdd(&s_td[(yy / CRIM_TILE - tty0) * 3 + (xx / CRIM_TILE - ttx0)], fn ? 1 : -1);
+        }
+    }
+    __syncthreads();
+    if (tid < 9) {
+        const int ti = tid / 3, tj = tid - 3 * ti;
+        const int delta = s_td[tid];
+        if (delta != 0 && tty0 + ti < p.tny && ttx0 + tj < p.tnx) {
+            int* tf = p.tfront + (size_t)b * p.tnx * p.tny;
+            int* tl = p.tlist + (size_t)b * p.tcap;
+            const int tile = (tty0 + ti) * p.tnx + ttx0 + tj;
+            const int now = tf_old + delta;
+            __hip_atomic_store(&tf[tile], now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tf_old == 0 && now > 0) {
+                const unsigned k = tcount0 + atomicAdd(&s_napp, 1u);
+                if (k < (unsigned)p.tcap) tl[k] = tile;
+                else s_ovf = 1;   // dropped: the list is rebuilt from the counts below
             }
         }
     }
@@ -2629,6 +2650,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PM <= 9 ? 8
             st->tcount = base;
             st->rebuilds += 1;
         }
+    } else if (tid == 0 && s_napp) {
+        st->tcount = tcount0 + s_napp;
     }
     // ---- loop state and trace
     if (tid == 0) {
