@@ -367,6 +367,8 @@ static void init_geometry(Params& p, int batch, int H, int W, int patch_size, un
     p.sny = (std::max(H - p.half, 1) + SB_H - 1) / SB_H;
     p.generic = ((flags & CRIM_FLAG_GENERIC_SEARCH) || !has_fast_search(p.P)) ? 1 : 0;
     p.dot4 = (flags & CRIM_FLAG_DOT4_SEARCH) ? 1 : 0;
+    // a candidate grid is at most W - half origins wide; the matrix-core kernels tile it 256 wide
+    p.scols = (p.generic || p.dot4) ? p.snx : (std::max(W - p.half, 1) + MS_W - 1) / MS_W;
     {
         // tuning knobs of the pipelined grey search, read when the engine is created
         const char* e = getenv("CRIM_PIPE_T");

@@ -2289,12 +2289,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PM <= 9 ? 8
     // The kernel is a chain of dependent memory round trips, so independent loads are issued
     // together.  Load batch 1: loop state, descriptor, and the partial arg-min list (read up to its
     // capacity; entries beyond the count are ignored once the count has arrived).
+    // The slots are visited in a compact order that skips the block columns the active tiling never
+    // uses: compact index c is block row c / scols, block column c % scols.
     const SEntry* sl = p.nparts > 0 ? p.xchg : p.slist + (size_t)b * p.snx * p.sny;
-    const int cap = p.nparts > 0 ? p.nparts : p.snx * p.sny;
+    const int scols = p.nparts > 0 ? p.nparts : p.scols;
+    const int srows = p.nparts > 0 ? 1 : p.sny;
+    const int sstride = p.nparts > 0 ? p.nparts : p.snx;
+    auto slot_of = [&](int c) { const int r = c / scols; return imin(r, srows - 1) * sstride + (c - r * scols); };
     constexpr int NSPEC = 4;
     SEntry spec[NSPEC];
 #pragma unroll
-    for (int k = 0; k < NSPEC; ++k) spec[k] = sl[imin(tid + 256 * k, cap - 1)];   // used only when in range
+    for (int k = 0; k < NSPEC; ++k) spec[k] = sl[slot_of(tid + 256 * k)];   // used only when in range
     const int live = st->live;
     // loop state is read once, up front: thread 0 rewrites it at the end of this kernel
     const int cur = st->cur;
@@ -2305,8 +2310,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PM <= 9 ? 8
     // inside the candidate grid
     const int grows = p.nparts > 0 ? 1 : (d->ncy + SB_H - 1) / SB_H;
     const int gcols = p.nparts > 0 ? p.nparts : search_cols(p, ncx);
-    const int gstride = p.nparts > 0 ? p.nparts : p.snx;
-    const int n = grows * gstride;
+    const int n = grows * scols;   // compact indices that can name a slot inside the candidate grid
     const int r0 = d->r0, c0 = d->c0, ph = d->ph, pw = d->pw;
     const double cnew = d->cnew;
     if (!live) return;
@@ -2404,14 +2408,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PM <= 9 ? 8
 #pragma unroll
     for (int k = 0; k < NSPEC; ++k) {
         const int i = tid + 256 * k;
-        if (i < n && i % gstride < gcols && better_cost(spec[k].cost, spec[k].idx, bc, bi)) {
+        if (i < n && i % scols < gcols && better_cost(spec[k].cost, spec[k].idx, bc, bi)) {
             bc = spec[k].cost; bi = spec[k].idx;
         }
     }
-    for (int i = tid + 256 * NSPEC; i < n; i += 256) {
-        if (i % gstride >= gcols) continue;
-        const SEntry e = sl[i];
-        if (better_cost(e.cost, e.idx, bc, bi)) { bc = e.cost; bi = e.idx; }
+    // what is left (large images only), four independent loads at a time
+    for (int i0 = tid + 256 * NSPEC; i0 < n; i0 += 256 * NSPEC) {
+        SEntry more[NSPEC];
+#pragma unroll
+        for (int k = 0; k < NSPEC; ++k) more[k] = sl[slot_of(imin(i0 + 256 * k, n - 1))];
+#pragma unroll
+        for (int k = 0; k < NSPEC; ++k) {
+            const int i = i0 + 256 * k;
+            if (i < n && i % scols < gcols && better_cost(more[k].cost, more[k].idx, bc, bi)) {
+                bc = more[k].cost; bi = more[k].idx;
+            }
+        }
     }
     for (int off = 32; off > 0; off >>= 1) {
         const double oc = __shfl_down(bc, off);

@@ -127,5 +127,6 @@ struct Params {
     const uint16_t* gamma_tab;
     const uint16_t* cbrt_tab;
     int coef[9];
+    int scols;         // most block columns of the active search tiling that can lie inside a candidate grid
     int selsearch;     // host side: the pipelined search also picks the target and builds the template (no k_select launch)
 };
