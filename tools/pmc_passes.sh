@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 run() {
   name=$1; shift
-  timeout -s KILL 150 rocprofv3 --pmc "$@" --output-format csv -d $R/gpurun_out/pmc_$name -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > $R/gpurun_out/pmc_$name.log 2>&1
+  timeout -s KILL 150 rocprofv3 --pmc "$@" --output-format csv -d $R/gpurun_out/pmc_$name -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --configs "" --no-host-io --no-split > $R/gpurun_out/pmc_$name.log 2>&1
   echo "pass $name exit=$?"
 }
 run valu SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY || exit 1
@@ -40,6 +40,6 @@ for k, v in summary.items():
                    "WRITE_SIZE_KB_per_launch": v["WRITE_SIZE_per_launch"],
                    "launches": v.get("launches_fetch"),
                    "images_per_launch": 4096,   # default bench batch 8192 on 2 lanes
-                   "command": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate runs) -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline"},
+                   "command": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate runs) -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --configs \"\" --no-host-io --no-split"},
                   open("$R/gpurun_out/pmc_search_latest.json", "w"), indent=1)
 PY
