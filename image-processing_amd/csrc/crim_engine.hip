@@ -289,8 +289,8 @@ static void launch_compact(const Params& p, hipStream_t s) {
 
 static size_t priority_lds_bytes(const Params& p) {
     const size_t rs = CRIM_TILE + 2 * p.half;
-    // records, front list (bytes), mask, per-lane offset table (4 x 15 pairs of 16-bit offsets), alignment slack
-    return rs * rs * 16 + CRIM_TILE * CRIM_TILE + (CRIM_TILE + 2) * (CRIM_TILE + 2) + 4 * 15 * 4 + 8;
+    // records, front list (bytes), mask, per-lane offset table (4 x 28 pairs of 16-bit offsets at most), alignment slack
+    return rs * rs * 16 + CRIM_TILE * CRIM_TILE + (CRIM_TILE + 2) * (CRIM_TILE + 2) + 4 * 28 * 4 + 8;
 }
 
 static void launch_update(const Params& p, hipStream_t s) {
@@ -308,6 +308,8 @@ static void launch_priority(const Params& p, hipStream_t s) {
         case 7: hipLaunchKernelGGL(k_priority<7>, grid, block, lds, s, p); break;
         case 9: hipLaunchKernelGGL(k_priority<9>, grid, block, lds, s, p); break;
         case 11: hipLaunchKernelGGL(k_priority<11>, grid, block, lds, s, p); break;
+        case 13: hipLaunchKernelGGL(k_priority<13>, grid, block, lds, s, p); break;
+        case 15: hipLaunchKernelGGL(k_priority<15>, grid, block, lds, s, p); break;
         default: hipLaunchKernelGGL(k_priority<0>, grid, block, lds, s, p); break;
     }
 }

@@ -608,9 +608,12 @@ __device__ __forceinline__ FrontEval finish_front_pixel(double cnew, const int n
 // its priority; the block emits its best (priority, position).
 //
 // PT > 0 is the compile-time patch edge of the fast path for pixels whose patch lies inside the
-// image (PT*PT <= 128, so NumPy's pairwise sum is a single 8-accumulator leaf): lane l of a group
-// owns accumulators 2l and 2l+1, i.e. flattened elements 8i + 2l + k, whose LDS offsets relative to
-// the patch corner are the same for every pixel and are computed once per kernel.  The same
+// image: lane l of a group owns accumulators 2l and 2l+1 of NumPy's 8-accumulator leaf, i.e.
+// flattened elements 8i + 2l + k, whose LDS offsets relative to the patch corner are the same for
+// every pixel and are computed once per kernel.  Up to 128 elements (PT <= 11) the pairwise sum is
+// one such leaf; 169 and 225 elements (PT 13, 15) are split once, at a multiple of 8 (80 | 89,
+// 112 | 113), and each half is a leaf of its own -- blocks [0, NA) and [NA, NE) of the same element
+// numbering -- whose sums are added last.  The same
 // elements feed the gradient scan: the largest key (4*|g|^2 << 10) | (1023 - e) is the first
 // maximum in flattened order.  Other pixels (clipped patches, larger PT) take the general path.
 template <int PT>
@@ -661,6 +664,9 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
     // per-lane-of-group table of record offsets (LDS, not registers: the registers buy a fourth
     // wave per SIMD): s_off[l][2i + k] = byte offset of flattened element 8i + 2l + k
     constexpr int NE = PT > 0 ? (PT * PT) / 8 : 1;
+    // blocks of 8 in the first half of the pairwise split (all of them when there is no split)
+    constexpr int NA = PT * PT <= 128 ? NE : ((PT * PT / 2) - (PT * PT / 2) % 8) / 8;
+    static_assert(PT * PT <= 256, "one split level: both halves are leaves");
     static_assert(CRIM_TILE * CRIM_TILE <= 256, "tile-local pixel indices are bytes");
     ushort2* s_off = (ushort2*)(((uintptr_t)(s_mask + MS * MS) + 3) & ~(uintptr_t)3);
     if (PT > 0) {
@@ -792,24 +798,38 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
                 double r0 = 0.0, r1 = 0.0;
                 unsigned best = 0;
                 const unsigned kb = 1023u - 2u * (unsigned)l;
-#pragma unroll 5
-                for (int i = 0; i < NE; ++i) {
+                auto block = [&](int i, bool first) {
                     const ushort2 o = s_off[l * NE + i];
                     const uint4 a = *(const uint4*)(eb + o.x);
                     const uint4 c = *(const uint4*)(eb + o.y);
                     const double ca = __hiloint2double((int)a.y, (int)a.x);
                     const double cc = __hiloint2double((int)c.y, (int)c.x);
-                    if (i == 0) { r0 = ca; r1 = cc; } else { r0 += ca; r1 += cc; }
+                    if (first) { r0 = ca; r1 = cc; } else { r0 += ca; r1 += cc; }
                     const unsigned ka = a.z + (kb - 8u * i), kc = c.z + (kb - 8u * i - 1u);
                     best = ka > best ? ka : best;
                     best = kc > best ? kc : best;
-                }
+                };
+                // the four lanes' accumulator pairs combined in NumPy's tree order
+                auto leaf_sum = [&]() {
+                    double t = r0 + r1;
+                    t = t + dpp_f64<DPP_QUAD_XOR1>(t);
+                    return t + dpp_f64<DPP_QUAD_XOR2>(t);
+                };
+#pragma unroll 5
+                for (int i = 0; i < NA; ++i) block(i, i == 0);
+                double t = leaf_sum();
                 constexpr int EL = PT * PT - 1;   // the one tail element: PT*PT = 1 (mod 8)
                 const uint4 tl_ = *(const uint4*)(eb + ((PT - 1) * RS + (PT - 1)) * 16);
-                double t = r0 + r1;
-                t = t + dpp_f64<DPP_QUAD_XOR1>(t);
-                t = t + dpp_f64<DPP_QUAD_XOR2>(t);
-                t += __hiloint2double((int)tl_.y, (int)tl_.x);
+                if constexpr (NA < NE) {
+                    // second half of the split: its own leaf, then its tail, then the halves are added
+#pragma unroll 5
+                    for (int i = NA; i < NE; ++i) block(i, i == NA);
+                    double t2 = leaf_sum();
+                    t2 += __hiloint2double((int)tl_.y, (int)tl_.x);
+                    t = t + t2;
+                } else {
+                    t += __hiloint2double((int)tl_.y, (int)tl_.x);
+                }
                 unsigned ob = (unsigned)dpp_i32<DPP_QUAD_XOR1>((int)best);
                 best = ob > best ? ob : best;
                 ob = (unsigned)dpp_i32<DPP_QUAD_XOR2>((int)best);
@@ -821,7 +841,7 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
                 const int bpk = (int)((const uint4*)eb)[brow * RS + bcol].w;
                 ev = finish_front_pixel(t / (double)p.psq, nb, F, bpk);
             } else {
-                ev = eval_front_pixel<(PT > 0 ? 0 : 3)>(p, vgrad, vconf, fy, fx, F, nb, l);
+                ev = eval_front_pixel<(PT > 0 ? (PT * PT > 128 ? 1 : 0) : 3)>(p, vgrad, vconf, fy, fx, F, nb, l);
             }
             if (l == 0) {
                 const int pos = fy * W + fx;
