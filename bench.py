@@ -331,27 +331,33 @@ def config_large(capi, device, side, patch, config_index, profile_iters=1500):
 # host-I/O-inclusive throughput of the headline batch
 # --------------------------------------------------------------------------------------------
 
-def streamed_images_per_s(capi, device, imgs, masks, steps, parts=4):
-    """The headline batch from and to page-locked host memory: `parts` engines of a share of the batch
-    each, one host thread per engine looping upload -> fill -> download.  One transfer phase at a time
-    (a lock), so the shares fall out of step and a share's PCIe transfers run under the other shares'
-    kernels."""
+def streamed_images_per_s(capi, device, imgs, masks, steps, shares=4, engines_n=5):
+    """The headline batch from and to page-locked host memory.  The batch is cut into `shares`
+    shares; `engines_n` engines of one share each (one host thread per engine) take shares from a
+    queue and loop upload -> fill -> download.  One transfer phase at a time (a lock), and one engine
+    more than there are shares in a batch: while an engine's transfers run, a batch's worth of images
+    is still being filled by the others."""
+    import queue
     B = len(imgs)
-    part = B // parts
+    part = B // shares
     pin_img, pin_msk, out = (capi.pinned_empty(imgs.shape), capi.pinned_empty(masks.shape),
                              capi.pinned_empty(imgs.shape))
     pin_img[:] = imgs
     pin_msk[:] = masks
     imgs, masks = pin_img, pin_msk
     engines = [capi.Engine(H, W, PATCH, batch=part, device=device, flags=capi.FLAG_NO_TRACE | capi.FLAG_ONE_LANE)
-               for _ in range(parts)]
+               for _ in range(engines_n)]
     errors = []
     link = threading.Lock()
 
-    def loop(k, n):
-        lo = k * part
+    def loop(k, work):
         try:
-            for _ in range(n):
+            while True:
+                try:
+                    share = work.get_nowait()
+                except queue.Empty:
+                    return
+                lo = share * part
                 with link:
                     engines[k].upload(imgs[lo:lo + part], masks[lo:lo + part])
                 engines[k].run()
@@ -360,8 +366,12 @@ def streamed_images_per_s(capi, device, imgs, masks, steps, parts=4):
         except Exception as e:            # noqa: BLE001 (reported to the main thread)
             errors.append(e)
 
-    def timed(n):
-        ts = [threading.Thread(target=loop, args=(k, n)) for k in range(parts)]
+    def timed(passes):
+        work = queue.Queue()
+        for _ in range(passes):
+            for sh in range(shares):
+                work.put(sh)
+        ts = [threading.Thread(target=loop, args=(k, work)) for k in range(engines_n)]
         t0 = time.perf_counter()
         for t in ts:
             t.start()
@@ -370,7 +380,7 @@ def streamed_images_per_s(capi, device, imgs, masks, steps, parts=4):
         return time.perf_counter() - t0
 
     try:
-        timed(1)
+        timed(2)
         dt = timed(steps)
         if errors:
             raise errors[0]
@@ -380,7 +390,7 @@ def streamed_images_per_s(capi, device, imgs, masks, steps, parts=4):
     result = out[:64].copy()
     for a in (imgs, masks, out):
         capi.pinned_free(a)
-    return parts * part * steps / dt, result
+    return shares * part * steps / dt, result
 
 
 def main():
@@ -552,8 +562,9 @@ def main():
         v, streamed_out = streamed_images_per_s(capi, local_rank, imgs, masks, args.steps)
         result["value_incl_host_io"] = v
         result["host_io_note"] = ("same batch from and to page-locked host memory (H2D 262144 B + D2H 196608 B per "
-                                  "image over PCIe): four engines of %d images on four host threads, upload -> fill -> "
-                                  "download each, one transfer phase at a time, %d passes" % (B // 4, args.steps))
+                                  "image over PCIe): the batch in four shares of %d images, five engines of one share each on five "
+                                  "host threads taking shares from a queue (upload -> fill -> download, one transfer "
+                                  "phase at a time), %d passes over the batch" % (B // 4, args.steps))
         if gpu_first is not None:
             result["host_io_outputs_identical"] = bool(np.array_equal(streamed_out[:len(gpu_first)], gpu_first))
         del streamed_out

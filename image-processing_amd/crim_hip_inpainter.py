@@ -82,6 +82,11 @@ class Criminisi_Inpainter():
         self.show_progress = show_progress
         self.device = device
 
+        if patch_size > 16:
+            import warnings
+            warnings.warn('patch_size %d: beyond 16 the reference\'s float32 sums of squared differences exceed '
+                          '2**24 and round; this engine keeps exact integers, so its choices can differ from '
+                          'the reference\'s there' % patch_size, stacklevel=2)
         self.iheight, self.iwidth = self.image.shape[:2]
         self.working_image = np.copy(self.image)
         self.working_mask = np.copy(self.mask)
@@ -94,11 +99,19 @@ class Criminisi_Inpainter():
         self.iterations = 0
 
     # front / data / priority (criminisi_inpainter.py:31,37,38) are materialised on demand: the
-    # fill loop never needs them as full frames.  After inpaint() they hold what the next
-    # iteration would compute from the final state.
+    # fill loop never needs them as full frames.  After inpaint() the reference holds the frames its
+    # LAST iteration computed before its update (:53-59); they are reproduced, when first read, by
+    # filling the same input once more up to the last iteration and evaluating the fields there.
     def _refresh_fields(self):
         if self._fields_stale and self._engine is not None:
-            f, d, p = self._engine.peek_fields(0)
+            img = np.ascontiguousarray(self.image, dtype=np.uint8)
+            mask_u8 = (np.asarray(self.mask) != 0).astype(np.uint8)
+            with capi.Engine(self.iheight, self.iwidth, self.patch_size, batch=1, device=self.device,
+                             flags=capi.FLAG_NO_TRACE) as eng:
+                eng.upload(img, mask_u8)
+                if self.iterations > 1:
+                    eng.run(max_iters=self.iterations - 1)
+                f, d, p = eng.peek_fields(0)
             self._front, self._data, self._priority = f, d, p
             self._fields_stale = False
 

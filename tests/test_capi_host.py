@@ -94,3 +94,16 @@ def test_product_does_not_import_oracle_or_cv2():
             assert "oracle" not in src.replace("# oracle", ""), fn
     src = open(os.path.join(ROOT, "src", "criminisi_inpainter.py")).read()
     assert "import cv2" not in src and "from oracle" not in src
+
+
+def test_shim_warns_beyond_the_exact_regime_of_the_reference():
+    import warnings
+    from src.criminisi_inpainter import Criminisi_Inpainter
+    img = np.zeros((40, 40, 3), np.uint8)
+    mask = np.zeros((40, 40), np.uint8)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        Criminisi_Inpainter(img, mask, patch_size=9)
+        assert not w
+        Criminisi_Inpainter(img, mask, patch_size=17)
+        assert len(w) == 1 and "float32" in str(w[0].message)

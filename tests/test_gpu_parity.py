@@ -397,7 +397,17 @@ def test_shim_class_end_to_end():
     assert np.array_equal(out, oout) and np.array_equal(ip.confidence, oconf)
     assert np.array_equal(img, img0) and np.array_equal(m, m0)      # inputs never mutated
     assert not ip.working_mask.any() and ip.iterations == n
-    assert ip.front.shape == (64, 64) and not ip.front.any()
+    # front / data / priority: what the reference's last iteration left there (computed before
+    # that iteration's update, :53-59)
+    o = CriminisiOracle(img0, m0, 9)
+    for _ in range(n - 1):
+        o.step()
+    o._find_front()
+    o._update_priorities()
+    assert np.array_equal(ip.front, o.front) and ip.front.any()
+    assert np.array_equal(ip.priority, o.priority)
+    fm = o.front > 0
+    assert np.array_equal(ip.data[fm], o.data[fm])
 
 
 def test_shim_verbose_and_show_progress_side_effects(tmp_path, monkeypatch, capsys):
