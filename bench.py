@@ -58,8 +58,11 @@ def host_cores():
     except (AttributeError, OSError):
         pass
     env = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
-    if env > 0:
+    if env > 1:                      # (1 is what torch.distributed.run sets by default: not a core count)
         n = min(n, env)
+    elif env == 1 and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        n = max(1, min(n, 16) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))) or 1)
+        n = max(n, 2)
     return max(1, n)
 
 
@@ -618,7 +621,7 @@ def main():
             dist.barrier()
         if rank == 0:
             sw.release(split_dir)
-            res = sw.summarise(sw.collect(split_dir, world, 600.0))
+            res = sw.summarise(sw.collect(split_dir, world, 240.0))
             res["note"] = ("configs[4], %d rank(s): every rank holds a replica of the 4096x4096 image, scores its share of "
                            "the window-origin rows and the ranks' best windows (16 B each) are exchanged by one RCCL "
                            "all-gather per iteration; us_per_iteration is the slowest rank's, over %d iterations after "
@@ -627,7 +630,7 @@ def main():
                            % (world, args.split_iters))
             result.setdefault("configs", {}).setdefault("configs[4]", {})["split_rccl"] = res
         try:
-            split_proc.wait(timeout=660)
+            split_proc.wait(timeout=30 if rank == 0 else 270)
         except Exception:                                   # noqa: BLE001
             split_proc.kill()
         if distributed:
