@@ -99,7 +99,8 @@ __device__ __forceinline__ nf_v2s nf_as_v2s(uint32_t v) { return __builtin_bit_c
 //   CH == 2 (the (a, b) image): lane 0 = a, lane 1 = b of one pixel; a window is 9 x 9 dwords;
 //   CH == 1 (L): lane 0 = L(y, x), lane 1 = L(y+1, x) (array V) -- a window is 9 columns of
 //     4 such pairs plus a last row taken from array Z (lane 1 = 0).
-// The pixel's own window stays in registers; the candidate windows are read from LDS.
+// The pixel's own window stays in registers, and so does the candidate window, which slides along a
+// row of the search area one column at a time.
 template <int CH>
 __global__ __launch_bounds__(256) void k_nf_nlm(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int H, int W,
                                                 const int* __restrict__ wtab, int nw, int shift) {
@@ -140,29 +141,53 @@ __global__ __launch_bounds__(256) void k_nf_nlm(const uint8_t* __restrict__ src,
 #pragma unroll
         for (int j = 0; j < NF_TW; ++j) T[r][j] = nf_as_v2s(elem(ty + NF_SWH, tx + NF_SWH, r, j));
     uint32_t est0 = 0, est1 = 0, wsum = 0;
+    // Candidate windows of one row of the search area (dy fixed, dx = 0 .. 30) overlap in 8 of their 9
+    // columns, so the window lives in registers as 9 column slots and every step of dx replaces one
+    // column (ROWS LDS reads instead of 9 * ROWS).  Slot k holds window column k at dx = 0 and is the
+    // one replaced after step dx when dx % 9 == k: at step dx, window column j sits in slot
+    // (j + dx) % 9 -- a compile-time index once the dx loop is unrolled by 9.
+    nf_v2s Wn[ROWS][NF_TW];
+    auto load_column = [&](int dy, int col, nf_v2s* dst_col /* stride NF_TW */) {
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) dst_col[r * NF_TW] = nf_as_v2s(elem(ty + dy, tx + col, r, 0));
+    };
+    auto account = [&](int dy, int dx, int dist) {
+        const int a = dist >> shift;
+        const uint32_t w = (uint32_t)(a < NF_WLDS ? s_w[a] : (a < nw ? wtab[a] : 0));
+        const int cy = ty + dy + NF_TWH, cx = tx + dx + NF_TWH;
+        if (CH == 2) {
+            const uint32_t v = sV[cy * NF_PITCH + cx];
+            est0 += w * (v & 0xffffu);
+            est1 += w * (v >> 16);
+        } else {
+            est0 += w * sZ[cy * NF_PITCH + cx];
+        }
+        wsum += w;
+    };
 #pragma unroll 1
     for (int dy = 0; dy < NF_SW; ++dy) {
+#pragma unroll
+        for (int j = 0; j < NF_TW; ++j) load_column(dy, j, &Wn[0][j]);
 #pragma unroll 1
-        for (int dx = 0; dx < NF_SW; ++dx) {
-            int dist = 0;
+        for (int dx0 = 0; dx0 < NF_SW; dx0 += NF_TW) {
 #pragma unroll
-            for (int r = 0; r < ROWS; ++r)
+            for (int k = 0; k < NF_TW; ++k) {
+                const int dx = dx0 + k;
+                if (dx < NF_SW) {            // the last group is shorter (31 = 3 * 9 + 4)
+                    int dist = 0;
 #pragma unroll
-                for (int j = 0; j < NF_TW; ++j) {
-                    const nf_v2s d = T[r][j] - nf_as_v2s(elem(ty + dy, tx + dx, r, j));
-                    dist = __builtin_amdgcn_sdot2(d, d, dist, false);
+                    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+                        for (int j = 0; j < NF_TW; ++j) {
+                            const nf_v2s d = T[r][j] - Wn[r][(j + k) % NF_TW];
+                            dist = __builtin_amdgcn_sdot2(d, d, dist, false);
+                        }
+                    account(dy, dx, dist);
+                    // window column 0 of this step is not part of the next one: its slot takes the
+                    // column that enters (window column 8 of step dx + 1 = region column dx + 9)
+                    if (dx + 1 < NF_SW) load_column(dy, dx + NF_TW, &Wn[0][k]);
                 }
-            const int a = dist >> shift;
-            const uint32_t w = (uint32_t)(a < NF_WLDS ? s_w[a] : (a < nw ? wtab[a] : 0));
-            const int cy = ty + dy + NF_TWH, cx = tx + dx + NF_TWH;
-            if (CH == 2) {
-                const uint32_t v = sV[cy * NF_PITCH + cx];
-                est0 += w * (v & 0xffffu);
-                est1 += w * (v >> 16);
-            } else {
-                est0 += w * sZ[cy * NF_PITCH + cx];
             }
-            wsum += w;
         }
     }
     const int ox = blockIdx.x * NF_TILE + tx, oy = blockIdx.y * NF_TILE + ty;
