@@ -425,7 +425,7 @@ extern "C" void crim_destroy(crim_t* h) {
     for (auto e : h->ev)
         if (e) (void)hipEventDestroy(e);
     Params& p = h->prm;
-    void* bufs[] = {p.bgr, p.planes, p.mask, p.grey, p.grad, p.conf, p.invalid, p.invbits, p.tfront, p.tlist, p.st,
+    void* bufs[] = {p.bgr, p.planes, p.mask, p.grey, p.grad, p.conf, p.dterm, p.invalid, p.invbits, p.tfront, p.tlist, p.st,
                     p.desc, p.plist, p.slist, p.xchg, p.trace, p.dbg, h->d_gamma, h->d_cbrt, h->d_peek};
     for (void* q : bufs)
         if (q) (void)hipFree(q);
@@ -469,6 +469,7 @@ extern "C" int crim_create_batch(int batch, int H, int W, int patch_size, int de
     alloc((void**)&p.grey, Bz * HW);
     alloc((void**)&p.grad, Bz * HW * sizeof(int));
     alloc((void**)&p.conf, Bz * 2 * HW * sizeof(double));
+    alloc((void**)&p.dterm, Bz * HW * sizeof(double));
     alloc((void**)&p.invalid, Bz * H * p.Wi);
     alloc((void**)&p.invbits, Bz * H * p.Wb * sizeof(unsigned long long));
     alloc((void**)&p.tfront, Bz * p.tnx * p.tny * sizeof(int));
@@ -1107,7 +1108,7 @@ extern "C" int crim_peek_fields(crim_t* h, int index, uint8_t* front_out, double
 // array (at its own address) until the process ends.  The array keeps the last call's contents:
 // whatever must start from a known value is cleared or rewritten at the top of each call.
 
-#define CRIM_NOALLOC_BYTES ((size_t)44 * CRIM_NOALLOC_MAX_PIXELS + ((size_t)1 << 18))
+#define CRIM_NOALLOC_BYTES ((size_t)52 * CRIM_NOALLOC_MAX_PIXELS + ((size_t)1 << 18))
 static __device__ __align__(256) unsigned char scratch[CRIM_NOALLOC_BYTES];
 
 namespace {
@@ -1179,6 +1180,7 @@ extern "C" int crim_inpaint_noalloc(int H, int W, int patch_size, int device, co
     c.take(&p.grey, HW);
     c.take(&p.grad, HW * sizeof(int));
     c.take(&p.conf, 2 * HW * sizeof(double));
+    c.take(&p.dterm, HW * sizeof(double));
     c.take(&p.invalid, invalid_bytes);
     c.take(&p.invbits, invbits_bytes);
     c.take(&p.tfront, (size_t)p.tnx * p.tny * sizeof(int));

@@ -214,6 +214,21 @@ __device__ __forceinline__ double pw_sum8<0>(const PatchReader& a, int lo, int n
 // must call this together and all receive the result).  conf is the confidence map before this
 // iteration's update, nb the pixel's 3x3 mask neighbourhood, F its front weight.
 // D is the halving depth of the pairwise sum: 0 when the patch is known to hold at most 128 pixels.
+// New confidence of a front pixel alone (criminisi_inpainter.py:114-127): the patch clipped to the
+// image, summed in NumPy's order by PG cooperating lanes, over patch_size squared.
+template <int D = 3>
+__device__ __forceinline__ double front_confidence(const Params& p, const View<double>& conf, int y, int x,
+                                                   int l) {
+    const int H = p.H, W = p.W, half = p.half;
+    const int r0 = imax(0, y - half), r1 = imin(y + half, H - 1);
+    const int c0 = imax(0, x - half), c1 = imin(x + half, W - 1);
+    const int ph = r1 - r0 + 1, pw = c1 - c0 + 1;
+    PatchReader rd;
+    rd.c = conf; rd.r0 = r0; rd.c0 = c0; rd.pw = pw;
+    rd.inv = (65536u + (unsigned)pw - 1u) / (unsigned)pw;
+    return pw_sum8<D>(rd, 0, ph * pw, l) / (double)p.psq;
+}
+
 template <int D = 3>
 __device__ __forceinline__ FrontEval eval_front_pixel(const Params& p, const View<int>& grad,
                                                       const View<double>& conf, int y, int x, int F,
@@ -632,9 +647,21 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
     // only keeps a reader inside the list whatever the count says)
     const int nt = imin((int)st->tcount, p.tcap);
     const int cur = st->cur;
+    // the patch the previous iteration filled: what changed since this kernel last ran
+    const int iter = st->iter;
+    const Desc* dlast = p.desc + b;
+    const int ur0 = dlast->r0, uc0 = dlast->c0, uph = dlast->ph, upw = dlast->pw;
     if (!live) return;
     const int H = p.H, W = p.W, half = p.half;
     const size_t HW = (size_t)H * W;
+    // The data term of a front pixel depends on the mask around it and on the gradient inside its
+    // patch, and an iteration changes the mask inside the filled patch and the gradient within one
+    // pixel of it: pixels farther than `half` from that box keep their data term, which is cached
+    // in p.dterm.  A tile is `fresh` when some pixel of it may need a new data term -- every tile
+    // on the first iteration -- and only fresh tiles stage the gradient and run the data-term code.
+    const int dy0 = iter == 0 ? 0 : ur0 - 1 - half, dy1 = iter == 0 ? H : ur0 + uph + half;
+    const int dx0 = iter == 0 ? 0 : uc0 - 1 - half, dx1 = iter == 0 ? W : uc0 + upw + half;
+    double* dterm = p.dterm + b * HW;
     STAMP_MID(1);
     if (bx >= nt) {
         if (threadIdx.x == 0) {
@@ -668,7 +695,9 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
     constexpr int NA = PT * PT <= 128 ? NE : ((PT * PT / 2) - (PT * PT / 2) % 8) / 8;
     static_assert(PT * PT <= 256, "one split level: both halves are leaves");
     static_assert(CRIM_TILE * CRIM_TILE <= 256, "tile-local pixel indices are bytes");
-    ushort2* s_off = (ushort2*)(((uintptr_t)(s_mask + MS * MS) + 3) & ~(uintptr_t)3);
+    // (an offset from the LDS base, not a pointer rounded up through an integer: that would make the
+    // table's accesses generic-address loads, which wait for every outstanding global access)
+    ushort2* s_off = (ushort2*)(smem + ((RS * RS * 16 + CRIM_TILE * CRIM_TILE + MS * MS + 3) & ~3));
     if (PT > 0) {
         for (int t = lane; t < PG * NE; t += 64) {
             const int ll = t / NE, i = t - ll * NE;
@@ -726,6 +755,7 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
         // Pixels beyond the image are never read (patches are clipped to it): their records are
         // filled from the clamped position.
         const int xx = imin(imax(rx0 + scol, 0), W - 1);
+        const bool fresh = ty0 <= dy1 && ty0 + CRIM_TILE - 1 >= dy0 && tx0 <= dx1 && tx0 + CRIM_TILE - 1 >= dx0;
         bool first = true, stale = false;
         for (int rb = srow; rb < RS; rb += NRB * rpp) {
             double cv[NRB];
@@ -738,7 +768,7 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
                 // (24-bit multiply: one full-rate instruction; H, W < 2^24)
                 const unsigned idx = __umul24((unsigned)yy, (unsigned)W) + (unsigned)xx;
                 cv[k] = *(const double*)((const char*)ccur + (size_t)(idx * 8u));
-                gv[k] = *(const int*)((const char*)grad + (size_t)(idx * 4u));
+                if (fresh) gv[k] = *(const int*)((const char*)grad + (size_t)(idx * 4u));
             }
             if (first) {
                 first = false;
@@ -748,16 +778,25 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
                     for (int k = 0; k < MSW; ++k) s_mask[(2 * k + (lane >> 5)) * MS + (lane & 31)] = mv[k];
                 }
             }
+            if (fresh) {
 #pragma unroll
-            for (int k = 0; k < NRB; ++k) {
-                const int row = rb + k * rpp;
-                if (row < RS && scol < RS) {
-                    const int gy2 = (int)(short)(gv[k] & 0xffff), gx2 = gv[k] >> 16;
-                    uint4 el;
-                    el.x = (uint32_t)__double2loint(cv[k]); el.y = (uint32_t)__double2hiint(cv[k]);
-                    el.z = (uint32_t)(gy2 * gy2 + gx2 * gx2) << 10;
-                    el.w = (uint32_t)gv[k];
-                    s_el[row * RS + scol] = el;
+                for (int k = 0; k < NRB; ++k) {
+                    const int row = rb + k * rpp;
+                    if (row < RS && scol < RS) {
+                        const int gy2 = (int)(short)(gv[k] & 0xffff), gx2 = gv[k] >> 16;
+                        uint4 el;
+                        el.x = (uint32_t)__double2loint(cv[k]); el.y = (uint32_t)__double2hiint(cv[k]);
+                        el.z = (uint32_t)(gy2 * gy2 + gx2 * gx2) << 10;
+                        el.w = (uint32_t)gv[k];
+                        s_el[row * RS + scol] = el;
+                    }
+                }
+            } else {
+                // the confidence half of each record only
+#pragma unroll
+                for (int k = 0; k < NRB; ++k) {
+                    const int row = rb + k * rpp;
+                    if (row < RS && scol < RS) *(double*)(s_el + row * RS + scol) = cv[k];
                 }
             }
         }
@@ -793,7 +832,46 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
                 for (int c = 0; c < 3; ++c) nb[a * 3 + c] = m0[a * MS + c];
             const int F = front_from_nb(nb);
             FrontEval ev;
-            if (PT > 0 && PG == 4 && fy >= half && fy + half < H && fx >= half && fx + half < W) {
+            const bool inside = fy >= half && fy + half < H && fx >= half && fx + half < W;
+            if (!fresh) {
+                // cached data term (requested before the sum, used after it)
+                const double dcached = dterm[fy * W + fx];
+                double cn;
+                if (PT > 0 && PG == 4 && inside) {
+                    const unsigned char* eb = (const unsigned char*)s_el + (py * RS + px) * 16;
+                    double r0 = 0.0, r1 = 0.0;
+                    auto block = [&](int i, bool first) {
+                        const ushort2 o = s_off[l * NE + i];
+                        const double ca = *(const double*)(eb + o.x);
+                        const double cc = *(const double*)(eb + o.y);
+                        if (first) { r0 = ca; r1 = cc; } else { r0 += ca; r1 += cc; }
+                    };
+                    auto leaf_sum = [&]() {
+                        double t = r0 + r1;
+                        t = t + dpp_f64<DPP_QUAD_XOR1>(t);
+                        return t + dpp_f64<DPP_QUAD_XOR2>(t);
+                    };
+#pragma unroll 5
+                    for (int i = 0; i < NA; ++i) block(i, i == 0);
+                    double t = leaf_sum();
+                    const double tl_ = *(const double*)(eb + ((PT - 1) * RS + (PT - 1)) * 16);
+                    if constexpr (NA < NE) {
+#pragma unroll 5
+                        for (int i = NA; i < NE; ++i) block(i, i == NA);
+                        double t2 = leaf_sum();
+                        t2 += tl_;
+                        t = t + t2;
+                    } else {
+                        t += tl_;
+                    }
+                    cn = t / (double)p.psq;
+                } else {
+                    cn = front_confidence<(PT > 0 ? (PT * PT > 128 ? 1 : 0) : 3)>(p, vconf, fy, fx, l);
+                }
+                ev.cnew = cn;
+                ev.data = dcached;
+                ev.prio = cn * dcached * (double)F;
+            } else if (PT > 0 && PG == 4 && inside) {
                 const unsigned char* eb = (const unsigned char*)s_el + (py * RS + px) * 16;
                 double r0 = 0.0, r1 = 0.0;
                 unsigned best = 0;
@@ -846,6 +924,7 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
             if (l == 0) {
                 const int pos = fy * W + fx;
                 cnxt[pos] = ev.cnew;
+                if (fresh) dterm[pos] = ev.data;
                 if (better_prio(ev.prio, pos, bestP, bestI)) { bestP = ev.prio; bestI = pos; }
             }
         }

@@ -129,4 +129,6 @@ struct Params {
     int coef[9];
     int scols;         // most block columns of the active search tiling that can lie inside a candidate grid
     int selsearch;     // host side: the pipelined search also picks the target and builds the template (no k_select launch)
+    double* dterm;     // [B][H][W] data term of a front pixel as last computed by the priority stage
+                       // (valid while nothing inside the pixel's patch has changed since)
 };
