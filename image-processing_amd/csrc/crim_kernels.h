@@ -723,15 +723,22 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
     // Rows of staging loads in flight per lane: the whole region when its edge is known at
     // compile time, batches of 16 otherwise.
     constexpr int NRB = PT > 0 ? (CRIM_TILE + PT - 1 + 1) / 2 : 16;
+    // The list entries are wave-uniform, and hipcc would wait for such a load on the spot to move the
+    // value to a scalar register -- a round trip before the tile's rows are even requested.  Indexed
+    // through a zero it cannot see through, the next entry travels with the tile's rows in a vector
+    // register and is made scalar once those have arrived.
+    int vzero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
     int tile_next = tile_first;
     for (int ti = bx; ti < nt; ti += p.pgrid) {
         if (ti == bx) STAMP_MID(4);
         const int tile = tile_next;
+        int tile_next_v = 0;
         // Dependent round trips are what this kernel waits on, so independent loads travel
         // together: the tile's front count (a stale list entry is dropped once it arrives), the
         // next list entry, the mask and the confidence / gradient rows.
         const int tfv = tf[tile];
-        if (ti + p.pgrid < nt) tile_next = tl[ti + p.pgrid];
+        if (ti + p.pgrid < nt) tile_next_v = tl[ti + p.pgrid + vzero];
         const int tY = tile / p.tnx, tX = tile - tY * p.tnx;
         const int ty0 = tY * CRIM_TILE, tx0 = tX * CRIM_TILE;
         const int ry0 = ty0 - half, rx0 = tx0 - half;
@@ -800,6 +807,7 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
                 }
             }
         }
+        tile_next = __builtin_amdgcn_readfirstlane(tile_next_v);
         if (stale) continue;
         __syncthreads();
         if (ti == bx) STAMP_MID(5);
