@@ -2087,18 +2087,33 @@ void k_search_pipe(Params p) {
     };
     v4i Bk[NS];
     v4i acc[R];
+    // Two row registers, refilled alternately: the read of row r + 2 is issued right after the matrix
+    // instructions of row r, so its LDS latency passes under those of row r + 1 (left to itself hipcc
+    // reads rows in pairs and waits for each pair with nothing in flight).
     auto plane_pass = [&](int slot, const v4i* Bf) {
         const uint8_t* base = &ring[slot][0] + aoff;
-#pragma unroll
-        for (int r = 0; r < NF; ++r) {
-            const v4i F = *(const v4i*)(base + r * MS_PITCH);
+        static_assert(NF % 2 == 0, "rows are consumed in pairs");
+        v4i Fa = *(const v4i*)(base), Fb = *(const v4i*)(base + MS_PITCH);
+        auto row = [&](int r, const v4i& F) {
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const int yy = r - 2 * s;
                 if (yy >= 0 && yy < R)
                     acc[yy] = __builtin_amdgcn_mfma_i32_16x16x64_i8(F, Bf[s], acc[yy], 0, 0, 0);
             }
+        };
+#pragma unroll
+        for (int r = 0; r < NF; r += 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            row(r, Fa);
+            __builtin_amdgcn_sched_barrier(0);
+            if (r + 2 < NF) Fa = *(const v4i*)(base + (r + 2) * MS_PITCH);
+            __builtin_amdgcn_sched_barrier(0);
+            row(r + 1, Fb);
+            __builtin_amdgcn_sched_barrier(0);
+            if (r + 3 < NF) Fb = *(const v4i*)(base + (r + 3) * MS_PITCH);
         }
+        __builtin_amdgcn_sched_barrier(0);
     };
     // the block's lowest cost of a tile is written by thread 0 one barrier after the waves posted theirs
     auto store_result = [&](int tb) {
