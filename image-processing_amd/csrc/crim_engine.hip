@@ -1076,6 +1076,22 @@ extern "C" int crim_debug_fill_tile_list(crim_t* h, int index) {
     return CRIM_OK;
 }
 
+// Diagnostic: the cached data terms of image `index` (H*W doubles; only entries of pixels that were
+// on the front when the priority stage last evaluated their tile mean anything).  Not part of the
+// public header.
+extern "C" int crim_debug_dterm(crim_t* h, int index, double* out) {
+    if (!h || !out) return fail(CRIM_ERR_ARG, "crim_debug_dterm: null argument");
+    const Params& p = h->prm;
+    if (index < 0 || index >= p.B) return fail(CRIM_ERR_ARG, "crim_debug_dterm: index %d of %d", index, p.B);
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (auto& ln : h->lanes)
+        if (ln.stream) HIP_TRY(hipStreamSynchronize(ln.stream));
+    const size_t HW = (size_t)p.H * p.W;
+    HIP_TRY(hipMemcpy(out, p.dterm + (size_t)index * HW, HW * sizeof(double), hipMemcpyDeviceToHost));
+    return CRIM_OK;
+}
+
 extern "C" int crim_peek_fields(crim_t* h, int index, uint8_t* front_out, double* data_out,
                                 double* priority_out) {
     if (!h) return fail(CRIM_ERR_ARG, "crim_peek_fields: null handle");

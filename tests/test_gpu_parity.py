@@ -302,6 +302,50 @@ def test_fields_match_numpy_oracle_mid_run():
             assert np.array_equal(msk[0], o.working_mask)
 
 
+def _debug_dterm(eng, H, W, index=0):
+    import ctypes
+    buf = np.zeros((H, W), np.float64)
+    lib = capi.load_library()
+    lib.crim_debug_dterm.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    rc = lib.crim_debug_dterm(eng._h, int(index), buf.ctypes.data)
+    assert rc == 0
+    return buf
+
+
+@pytest.mark.parametrize("patch,shape", [(9, (96, 112)), (5, (70, 64)), (15, (100, 90))])
+def test_cached_data_terms_equal_fresh_ones(patch, shape):
+    """The priority stage recomputes a front pixel's data term only in 16x16 tiles within reach of
+    the patch the previous iteration filled and reads every other front pixel's from a cache.
+    After each of a number of iterations: every front pixel of a tile the next priority launch will
+    NOT recompute must hold, in the cache, exactly the data term a full-frame evaluation gives."""
+    H, W = shape
+    img = crim_synth.xray_like(H, W, 8200 + patch, colour=True)
+    m = crim_synth.blob_mask(H, W, 8200 + patch, 0.18, patch)
+    half = (patch - 1) // 2
+    checked = 0
+    with capi.Engine(H, W, patch) as eng:
+        eng.upload(img, m)
+        for it in range(1, 40):
+            done, rem = eng.run(max_iters=1)
+            if rem == 0:
+                break
+            tr = eng.trace(0)[-1]
+            r0, c0 = max(0, int(tr["tr"]) - half), max(0, int(tr["tc"]) - half)
+            r1, c1 = min(int(tr["tr"]) + half, H - 1), min(int(tr["tc"]) + half, W - 1)
+            front, data, prio = eng.peek_fields(0)
+            cache = _debug_dterm(eng, H, W)
+            # tiles the next launch recomputes: those meeting the filled box grown by half + 1
+            y0, y1, x0, x1 = r0 - 1 - half, r1 + 1 + half, c0 - 1 - half, c1 + 1 + half
+            ys, xs = np.nonzero(front)
+            for y, x in zip(ys, xs):
+                ty, tx = (y // 16) * 16, (x // 16) * 16
+                fresh = ty <= y1 and ty + 15 >= y0 and tx <= x1 and tx + 15 >= x0
+                if not fresh:
+                    assert cache[y, x] == data[y, x], (it, y, x)
+                    checked += 1
+    assert checked > 200
+
+
 def _debug_state(eng, index=0):
     import ctypes
     buf = (ctypes.c_int * 16)()
