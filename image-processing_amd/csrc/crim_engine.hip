@@ -17,6 +17,13 @@
 
 #include "crim_kernels.h"
 
+// diagnostic stamp buffer: 64 named slots (plus per-block records in -DCRIM_STAMPS builds)
+#ifdef CRIM_STAMPS
+static constexpr size_t kDbgSlots = 64 + 8192;
+#else
+static constexpr size_t kDbgSlots = 64;
+#endif
+
 // ------------------------------------------------------------------------------------------
 // errors
 // ------------------------------------------------------------------------------------------
@@ -478,7 +485,7 @@ extern "C" int crim_create_batch(int batch, int H, int W, int patch_size, int de
     alloc((void**)&p.desc, Bz * sizeof(Desc));
     alloc((void**)&p.plist, Bz * p.pgrid * sizeof(PEntry));
     alloc((void**)&p.slist, Bz * p.snx * p.sny * sizeof(SEntry));
-    alloc((void**)&p.dbg, 64 * sizeof(long long));
+    alloc((void**)&p.dbg, kDbgSlots * sizeof(long long));
     alloc((void**)&p.xchg, 64 * sizeof(SEntry));
     alloc((void**)&h->d_gamma, sizeof(t.gamma));
     alloc((void**)&h->d_cbrt, sizeof(t.cbrt_));
@@ -490,7 +497,7 @@ extern "C" int crim_create_batch(int batch, int H, int W, int patch_size, int de
     if (e == hipSuccess) e = hipMemset(p.invalid, 1, Bz * H * p.Wi);
     if (e == hipSuccess) e = hipMemset(p.invbits, 0xff, Bz * H * p.Wb * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(p.st, 0, Bz * sizeof(ImgState));
-    if (e == hipSuccess) e = hipMemset(p.dbg, 0, 64 * sizeof(long long));
+    if (e == hipSuccess) e = hipMemset(p.dbg, 0, kDbgSlots * sizeof(long long));
     if (e == hipSuccess) e = hipMemset(p.desc, 0, Bz * sizeof(Desc));
     if (e != hipSuccess) {
         const int code = fail(e == hipErrorOutOfMemory ? CRIM_ERR_NOMEM : CRIM_ERR_HIP,
@@ -1035,6 +1042,17 @@ extern "C" int crim_profile(crim_t* h, double* search_ms, long* search_launches,
 
 // Diagnostic: copies the 64 stamp slots (see STAMP in crim_kernels.h); zeros unless the library
 // was built with -DCRIM_STAMPS.  Not part of the public header.
+#ifdef CRIM_STAMPS
+// Diagnostic build only: the per-block entry / end records of the last pipelined search launch.
+extern "C" int crim_debug_block_stamps(crim_t* h, long long* out8192) {
+    if (!h || !out8192) return fail(CRIM_ERR_ARG, "crim_debug_block_stamps: null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(out8192, h->prm.dbg + 64, 8192 * sizeof(long long), hipMemcpyDeviceToHost));
+    return CRIM_OK;
+}
+#endif
+
 extern "C" int crim_debug_stamps(crim_t* h, long long* out64) {
     if (!h || !out64) return fail(CRIM_ERR_ARG, "crim_debug_stamps: null argument");
     HIP_TRY(hipSetDevice(h->device));
@@ -1205,7 +1223,7 @@ extern "C" int crim_inpaint_noalloc(int H, int W, int patch_size, int device, co
     c.take(&p.desc, sizeof(Desc));
     c.take(&p.plist, (size_t)p.pgrid * sizeof(PEntry));
     c.take(&p.slist, (size_t)p.snx * p.sny * sizeof(SEntry));
-    c.take(&p.dbg, 64 * sizeof(long long));
+    c.take(&p.dbg, kDbgSlots * sizeof(long long));
     c.take(&p.xchg, 64 * sizeof(SEntry));
     c.take(&d_gamma, sizeof(t.gamma));
     c.take(&d_cbrt, sizeof(t.cbrt_));

@@ -24,9 +24,16 @@
         if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2 + 5)                            \
             p.dbg[slot] = wall_clock64();                                                   \
     } while (0)
+// per-block records beyond the 64 named slots: entry (which = 0) and end (which = 1) of every block of a
+// launch of at most 4096 blocks
+#define STAMP_BLOCK(which)                                                                  \
+    do {                                                                                    \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) p.dbg[64 + 2 * blockIdx.x + (which)] = wall_clock64(); \
+    } while (0)
 #else
 #define STAMP(slot) do {} while (0)
 #define STAMP_MID(slot) do {} while (0)
+#define STAMP_BLOCK(which) do {} while (0)
 #endif
 
 // ------------------------------------------------------------------------------------------
@@ -1506,6 +1513,7 @@ void k_search_mfma(Params p) {
     if (y0 >= ncy || x0 >= ncx) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     STAMP_MID(32);
+    STAMP_BLOCK(0);
     if (tid == 0) s_bound = __hip_atomic_load(&p.st[b].bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int H = p.H, W = p.W;
     const size_t HW = (size_t)H * W;
@@ -1862,6 +1870,8 @@ void k_search_pipe(Params p) {
     const int b = p.b0 + img_;
     const Desc* __restrict__ d = p.desc + b;
     // SELECT: k*T and k of the target patch, flattened row-major with row length P
+    STAMP_MID(32);
+    STAMP_BLOCK(0);
     __shared__ uint8_t s_sk[SELECT ? P * P : 1];
     __shared__ int8_t s_st[SELECT ? 3 : 1][SELECT ? P * P : 1];
     __shared__ double s_sp[SELECT ? 4 : 1];
@@ -1912,6 +1922,7 @@ void k_search_pipe(Params p) {
 #pragma unroll
         for (int w = 1; w < 4; ++w)
             if (better_prio(s_sp[w], s_si[w], bestP, bestI)) { bestP = s_sp[w]; bestI = s_si[w]; }
+        STAMP_MID(33);
         const int pos = bestP > 0.0 ? bestI : 0;
         const int tr = pos / W, tc = pos - tr * W;
         const int r1 = imin(tr + p.half, H - 1), c1 = imin(tc + p.half, W - 1);
@@ -1992,11 +2003,31 @@ void k_search_pipe(Params p) {
     uint32_t boff = umin_u32((uint32_t)(tb0 * MS_ROWS + (tid >> 3)) * bstep + ((x0 >> 6) * 8 + (tid & 7) * 4), bmax);
     auto load_bits = [&](uint32_t off) { gload_lds4(ivb, off, vbits_lds); };
 
+    // SELECT: the target patch's pixels (mask, L, a, b) are requested ahead of the tiles, so that they
+    // return first (loads return in order) and the template is built while the tiles are still
+    // travelling.  The requests are inline assembly, as the ring loads are: hipcc would count only its
+    // own loads and wait for nearly all of the ring's before the first use.
+    uint32_t sel_em = 0, sel_e0 = 0, sel_e1 = 0, sel_e2 = 0;
+    if constexpr (SELECT) {
+        const int e = imin(tid, P * P - 1);
+        const int i = e / P, j = e - i * P;
+        const int yy = imin(sel.r0 + i, H - 1), xx = imin(sel.c0 + j, W - 1);
+        const uint32_t mo = (uint32_t)(yy * W + xx), po = (uint32_t)(yy * Wp + xx);
+        asm volatile("global_load_ubyte %0, %1, %2" : "=v"(sel_em) : "v"(mo), "s"(mask) : "memory");
+        asm volatile("global_load_sbyte %0, %1, %2" : "=v"(sel_e0) : "v"(po), "s"(pl) : "memory");
+        asm volatile("global_load_sbyte %0, %1, %2" : "=v"(sel_e1) : "v"(po), "s"(pl + plane_bytes) : "memory");
+        asm volatile("global_load_sbyte %0, %1, %2" : "=v"(sel_e2) : "v"(po), "s"(pl + 2 * plane_bytes) : "memory");
+    }
     // prologue: the first three planes of the first tile; template rows into LDS
     load_plane(plane_of(0), coff, 0);
     load_bits(boff);
     load_plane(plane_of(1), coff, 1);
     load_plane(plane_of(2), coff, 2);
+    if constexpr (SELECT) {
+        // the four patch loads have returned once at most the 3 NK + 1 ring loads behind them are outstanding
+        constexpr int BEHIND = 3 * NK + 1;
+        asm volatile("s_waitcnt vmcnt(%4)" : "+v"(sel_em), "+v"(sel_e0), "+v"(sel_e1), "+v"(sel_e2) : "n"(BEHIND) : "memory");
+    }
     constexpr int NZ = (NCC + 1) * 2 * NS;
     static_assert(NZ <= 256, "one template row per thread");
     if constexpr (!SELECT) {
@@ -2015,10 +2046,8 @@ void k_search_pipe(Params p) {
         {
             const int e = imin(tid, P * P - 1);
             const int i = e / P, j = e - i * P;
-            const int yy = imin(sel.r0 + i, H - 1), xx = imin(sel.c0 + j, W - 1);
-            const int em = mask[(size_t)yy * W + xx];
-            const size_t o = (size_t)yy * Wp + xx;
-            const int e0 = (int8_t)pl[o], e1 = (int8_t)pl[plane_bytes + o], e2 = (int8_t)pl[2 * plane_bytes + o];
+            const int em = (int)sel_em;
+            const int e0 = (int)sel_e0, e1 = (int)sel_e1, e2 = (int)sel_e2;
             int soff_l = 0, nk_l = 0, rowm_l = 0, chm_l = 0;
             if (tid < P * P) {
                 int k = 0, t0 = 0, t1 = 0, t2 = 0;
@@ -2069,6 +2098,7 @@ void k_search_pipe(Params p) {
         }
     }
 
+    STAMP_MID(34);
     const int g = lane >> 4;
     const int aoff = (wv * R + (g >> 1)) * MS_PITCH + 16 * ((lane & 15) + (g & 1));
     const int zoff = (g >> 1) * 48 + 16 + 16 * (g & 1) - (lane & 15);
@@ -2174,6 +2204,7 @@ void k_search_pipe(Params p) {
                 }
             }
             if (j == 0) {
+                if (t == 0) STAMP_MID(35);
                 if (t > 0 && tid == 0) store_result(tb - 1);
                 if (t == 0) fragments(NCC, Bk);
                 // every wave looks at the whole tile's validity words: is there any admissible window?
@@ -2229,6 +2260,7 @@ void k_search_pipe(Params p) {
             }
         }
 
+        if (t == 0) STAMP_MID(36);
         // pricing, as in k_search_mfma
         double bc = INFINITY;
         unsigned bi = 0xffffffffu;
@@ -2246,6 +2278,7 @@ void k_search_pipe(Params p) {
         }
         publish_barrier<63>();                      // bounds posted; no ring load is waited for
         if (more) load_plane(plane_of(2), coff, slot_of(NP + 2));   // the last pass's slot takes load NP + 2
+        if (t == 0) STAMP_MID(37);
         const int ub = __hip_atomic_load(&s_bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const long long lim = (long long)soff - ub;
         const int thr = lim < -(long long)(POISON << 7) + 1 ? -(POISON << 7) + 1 : (int)lim;
@@ -2287,6 +2320,8 @@ void k_search_pipe(Params p) {
         const int ub = s_bound;
         if (ub < bound0) atomicMin(&p.st[b].bound, ub);
     }
+    STAMP_MID(38);
+    STAMP_BLOCK(1);
 }
 
 // Unspecialised search for any patch edge: one origin at a time, planes read from global
