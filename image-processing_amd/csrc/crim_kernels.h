@@ -102,6 +102,47 @@ __device__ __forceinline__ int wave_max_i32(int v) {
 }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 
+// The same ladder for a (key, index) pair under a strict total order `better(ka, ia, kb, ib)` (is a
+// better than b): arg-max of the priority stage, arg-min of the search.  Every lane receives the
+// wave's best pair.  Six DPP steps of three moves each, against six ds_bpermute round trips of a
+// shuffle-based reduction.
+template <int CTRL, int ROWS>
+__device__ __forceinline__ int dpp_rows_i32(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, ROWS, 0xf, false);   // lanes of other rows keep v
+}
+template <typename Better>
+__device__ __forceinline__ void wave_best_pair(double& k, int& i, Better better) {
+#define CRIM_PAIR_STEP(CTRL, ROWS)                                                                   \
+    {                                                                                                \
+        const double ok = __hiloint2double(dpp_rows_i32<CTRL, ROWS>(__double2hiint(k)),              \
+                                           dpp_rows_i32<CTRL, ROWS>(__double2loint(k)));             \
+        const int oi = dpp_rows_i32<CTRL, ROWS>(i);                                                  \
+        if (better(ok, oi, k, i)) { k = ok; i = oi; }                                                \
+    }
+    CRIM_PAIR_STEP(DPP_QUAD_XOR1, 0xf)
+    CRIM_PAIR_STEP(DPP_QUAD_XOR2, 0xf)
+    CRIM_PAIR_STEP(0x141, 0xf)   // row_half_mirror
+    CRIM_PAIR_STEP(0x140, 0xf)   // row_mirror: every lane holds its row's best
+    CRIM_PAIR_STEP(0x142, 0xa)   // row_bcast15 into rows 1, 3
+    CRIM_PAIR_STEP(0x143, 0xc)   // row_bcast31 into rows 2, 3: lane 63 holds the wave's best
+#undef CRIM_PAIR_STEP
+    k = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(k), 63), __builtin_amdgcn_readlane(__double2loint(k), 63));
+    i = __builtin_amdgcn_readlane(i, 63);
+}
+// Sum / bitwise OR over the 64 lanes of a wave, returned to every lane (lanes of rows a broadcast
+// step does not reach contribute 0 there).
+template <bool OR>
+__device__ __forceinline__ int wave_fold_i32(int v) {
+    auto f = [](int a, int b) { return OR ? (a | b) : (a + b); };
+    v = f(v, __builtin_amdgcn_update_dpp(0, v, DPP_QUAD_XOR1, 0xf, 0xf, false));
+    v = f(v, __builtin_amdgcn_update_dpp(0, v, DPP_QUAD_XOR2, 0xf, 0xf, false));
+    v = f(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false));
+    v = f(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false));
+    v = f(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false));
+    v = f(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 // A rectangular window of a 2-D field: element (y, x) in image coordinates lives `stride` bytes
 // apart at base + ((y - oy) * pitch + (x - ox)) * stride.  The same code reads whole frames in
 // global memory (oy = ox = 0, pitch = W, stride = sizeof(T)) and the interleaved records of a tile
@@ -948,11 +989,7 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
     }
     STAMP_MID(2);
     // wave arg-max: highest priority, lowest row-major index on ties (np.argmax, :217)
-    for (int off_ = 32; off_ > 0; off_ >>= 1) {
-        const double op = __shfl_down(bestP, off_);
-        const int oi = __shfl_down(bestI, off_);
-        if (better_prio(op, oi, bestP, bestI)) { bestP = op; bestI = oi; }
-    }
+    wave_best_pair(bestP, bestI, [](double pa, int ia, double pb, int ib) { return better_prio(pa, ia, pb, ib); });
     // every wave owns one slot of its image's partial list (an empty entry has priority -1)
     if (lane == 0) {
         PEntry e;
@@ -1039,11 +1076,7 @@ __global__ __launch_bounds__(256) void k_select(Params p) {
         const PEntry e = pl[i];
         if (better_prio(e.prio, e.pos, bestP, bestI)) { bestP = e.prio; bestI = e.pos; }
     }
-    for (int off = 32; off > 0; off >>= 1) {
-        const double op = __shfl_down(bestP, off);
-        const int oi = __shfl_down(bestI, off);
-        if (better_prio(op, oi, bestP, bestI)) { bestP = op; bestI = oi; }
-    }
+    wave_best_pair(bestP, bestI, [](double pa, int ia, double pb, int ib) { return better_prio(pa, ia, pb, ib); });
     if ((tid & 63) == 0) { s_bp[tid >> 6] = bestP; s_bi[tid >> 6] = bestI; }
     if (tid == 0) { s_soff = 0; s_rowmask = 0; s_chmask = 0; s_nk = 0; }
     __syncthreads();
@@ -1106,13 +1139,10 @@ __global__ __launch_bounds__(256) void k_select(Params p) {
         }
     }
     if (__any(nk_local != 0)) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            soff_local += __shfl_xor(soff_local, off);
-            nk_local += __shfl_xor(nk_local, off);
-            rowm_local |= __shfl_xor(rowm_local, off);
-            chm_local |= __shfl_xor(chm_local, off);
-        }
+        soff_local = wave_fold_i32<false>(soff_local);
+        nk_local = wave_fold_i32<false>(nk_local);
+        rowm_local = wave_fold_i32<true>(rowm_local);
+        chm_local = wave_fold_i32<true>(chm_local);
         if ((tid & 63) == 0) {
             atomicAdd(&s_soff, soff_local);
             atomicAdd(&s_nk, nk_local);
@@ -1236,10 +1266,10 @@ __device__ __forceinline__ void emit_empty(const Params& p, int b, int slot) {
 __device__ __forceinline__ void block_min_emit(const Params& p, int b, int slot, double bc, unsigned bi,
                                                double* s_c, unsigned* s_i) {
     const int tid = threadIdx.x;
-    for (int off = 32; off > 0; off >>= 1) {
-        const double oc = __shfl_down(bc, off);
-        const unsigned oi = __shfl_down(bi, off);
-        if (better_cost(oc, oi, bc, bi)) { bc = oc; bi = oi; }
+    {
+        int bi_ = (int)bi;
+        wave_best_pair(bc, bi_, [](double ca, int ia, double cb, int ib) { return better_cost(ca, (unsigned)ia, cb, (unsigned)ib); });
+        bi = (unsigned)bi_;
     }
     if ((tid & 63) == 0) { s_c[tid >> 6] = bc; s_i[tid >> 6] = bi; }
     __syncthreads();
@@ -1910,11 +1940,7 @@ void k_search_pipe(Params p) {
             const PEntry e = pl_[i];
             if (better_prio(e.prio, e.pos, bestP, bestI)) { bestP = e.prio; bestI = e.pos; }
         }
-        for (int off = 32; off > 0; off >>= 1) {
-            const double op = __shfl_down(bestP, off);
-            const int oi = __shfl_down(bestI, off);
-            if (better_prio(op, oi, bestP, bestI)) { bestP = op; bestI = oi; }
-        }
+        wave_best_pair(bestP, bestI, [](double pa, int ia, double pb, int ib) { return better_prio(pa, ia, pb, ib); });
         if (lane == 0) { s_sp[wv] = bestP; s_si[wv] = bestI; }
         if (tid < 4) s_red[tid] = 0;
         __syncthreads();
@@ -2062,13 +2088,10 @@ void k_search_pipe(Params p) {
                 s_sk[tid] = (uint8_t)k;
                 s_st[0][tid] = (int8_t)t0; s_st[1][tid] = (int8_t)t1; s_st[2][tid] = (int8_t)t2;
             }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                soff_l += __shfl_xor(soff_l, off);
-                nk_l += __shfl_xor(nk_l, off);
-                rowm_l |= __shfl_xor(rowm_l, off);
-                chm_l |= __shfl_xor(chm_l, off);
-            }
+            soff_l = wave_fold_i32<false>(soff_l);
+            nk_l = wave_fold_i32<false>(nk_l);
+            rowm_l = wave_fold_i32<true>(rowm_l);
+            chm_l = wave_fold_i32<true>(chm_l);
             if (lane == 0 && nk_l) {
                 atomicAdd(&s_red[0], soff_l);
                 atomicAdd(&s_red[1], nk_l);
@@ -2392,10 +2415,10 @@ __global__ __launch_bounds__(256) void k_local_best(Params p, int part, int row0
         const SEntry e = sl[i];
         if (better_cost(e.cost, e.idx, bc, bi)) { bc = e.cost; bi = e.idx; }
     }
-    for (int off = 32; off > 0; off >>= 1) {
-        const double oc = __shfl_down(bc, off);
-        const unsigned oi = __shfl_down(bi, off);
-        if (better_cost(oc, oi, bc, bi)) { bc = oc; bi = oi; }
+    {
+        int bi_ = (int)bi;
+        wave_best_pair(bc, bi_, [](double ca, int ia, double cb, int ib) { return better_cost(ca, (unsigned)ia, cb, (unsigned)ib); });
+        bi = (unsigned)bi_;
     }
     if ((tid & 63) == 0) { s_c[tid >> 6] = bc; s_i[tid >> 6] = bi; }
     __syncthreads();
@@ -2582,10 +2605,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PM <= 9 ? 8
             }
         }
     }
-    for (int off = 32; off > 0; off >>= 1) {
-        const double oc = __shfl_down(bc, off);
-        const unsigned oi = __shfl_down(bi, off);
-        if (better_cost(oc, oi, bc, bi)) { bc = oc; bi = oi; }
+    {
+        int bi_ = (int)bi;
+        wave_best_pair(bc, bi_, [](double ca, int ia, double cb, int ib) { return better_cost(ca, (unsigned)ia, cb, (unsigned)ib); });
+        bi = (unsigned)bi_;
     }
     if ((tid & 63) == 0) { s_c[tid >> 6] = bc; s_i[tid >> 6] = bi; }
     if (tid == 0) { s_filled = 0; s_ovf = 0; s_napp = 0u; }
