@@ -2451,8 +2451,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PM <= 9 ? 8
     constexpr int GR = PM + 4;        // grey region edge for the gradient update
     __shared__ double s_c[4];
     __shared__ unsigned s_i[4];
-    __shared__ unsigned s_src;
-    __shared__ double s_cost;
     __shared__ int s_filled;
     __shared__ uint8_t s_px[PM * PM][4 + CRIM_NPL];   // source pixel: B,G,R, the planes, grey
     __shared__ uint8_t s_m[MR * MR];    // mask around the patch, updated as pixels are filled
@@ -2615,16 +2613,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PM <= 9 ? 8
     if (tid < 9) s_td[tid] = 0;
     if (tid < (PM * PM + 31) / 32) s_fill[tid] = 0;
     __syncthreads();
-    if (tid == 0) {
-        for (int w = 1; w < 4; ++w)
-            if (better_cost(s_c[w], s_i[w], bc, bi)) { bc = s_c[w]; bi = s_i[w]; }
-        // no admissible window: every cost is +inf and np.argmin returns index 0
-        s_src = (bi == 0xffffffffu) ? 0u : bi;
-        s_cost = bc;
-    }
-    __syncthreads();
+    // every thread combines the four waves' results itself: one barrier instead of two
+    bc = s_c[0]; bi = s_i[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+        if (better_cost(s_c[w], s_i[w], bc, bi)) { bc = s_c[w]; bi = s_i[w]; }
+    // no admissible window: every cost is +inf and np.argmin returns index 0
+    const unsigned src = (bi == 0xffffffffu) ? 0u : bi;
+    const double src_cost = bc;
     STAMP(17);
-    const int sy = (int)(s_src / (unsigned)ncx), sx = (int)(s_src % (unsigned)ncx);
+    const int sy = (int)(src / (unsigned)ncx), sx = (int)(src % (unsigned)ncx);
 
     // Load batch 3 (needs the source position): the source pixels.
     for (int e = tid; e < ph * pw; e += 256) {
@@ -2732,15 +2730,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PM <= 9 ? 8
     // (a filled pixel next to still-masked ones) or leave it (its masked diagonal neighbours
     // were all filled)
     {
+        // Only this block changes its image's counts, so they need no global atomics: the changes are
+        // summed per tile in LDS, and one thread per tile applies them to the count it requested with
+        // the first batch of loads.  A tile enters the list when its count leaves zero.
         auto MN = [&](int y2, int x2) -> int {
             return (int)s_m[(reflect101(y2, H) - mr0) * MR + (reflect101(x2, W) - mc0)];
         };
         auto MO = [&](int y2, int x2) -> int {
             return (int)s_m0[(reflect101(y2, H) - mr0) * MR + (reflect101(x2, W) - mc0)];
         };
-        // Only this block changes its image's counts, so they need no global atomics: the changes are
-        // summed per tile in LDS, and one thread per tile applies them to the count it requested with
-        // the first batch of loads.  A tile enters the list when its count leaves zero.
         const int fh = ph + 2, fw = pw + 2;
         for (int e = tid; e < fh * fw; e += 256) {
             const int i = e / fw, j = e - i * fw;
@@ -2853,7 +2851,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PM <= 9 ? 8
         if (p.trace && it < p.trace_cap) {
             crim_iter_rec rec;
             rec.tr = d->tr; rec.tc = d->tc; rec.sy = sy; rec.sx = sx;
-            rec.cost = s_cost; rec.remaining = rem;
+            rec.cost = src_cost; rec.remaining = rem;
             p.trace[(size_t)b * p.trace_cap + it] = rec;
         }
         st->remaining = rem;
