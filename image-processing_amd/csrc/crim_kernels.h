@@ -2005,7 +2005,9 @@ void k_search_pipe(Params p) {
     uint32_t coff[NK];            // this tile's chunk offsets
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
-        const int c = tid + k * 256;
+        // (a chunk beyond the tile -- slot padding, or a load that lands in `dump` -- asks again for the
+        // chunk of this thread's first load: a cache hit instead of rows nobody reads)
+        const int c = tid + k * 256 < NCH ? tid + k * 256 : tid;
         const int row = c / C16;
         const int gx = imin(x0 + 16 * (c - row * C16), Wp - 16);
         coff[k] = (uint32_t)(tb0 * MS_ROWS + row) * Wp + gx;
@@ -2196,12 +2198,20 @@ void k_search_pipe(Params p) {
             default: publish_barrier<63>(); break;
         }
     };
+    // A wave is `clean` in a tile when every window of its rows left of the image's right edge is
+    // admissible and that edge cuts at most the last of a lane's four windows: its accumulators then
+    // start from zero (no start values worked out per window) and the edge windows are taken out
+    // after the passes.
+    const int edge_lim = ncx - x0;                       // columns [edge_lim, 256) of the tile lie beyond the edge
+    const bool edge_ok = !clipped && edge_lim >= 240;
+    const unsigned long long edge_word = edge_lim >= 256 ? 0ull : ~0ull << (imax(edge_lim, 192) - 192);
     for (int t = 0; t < T; ++t) {
         const unsigned long long* vb = vbits;
         const int tb = tb0 + t;
         const int wy = tb * MS_ROWS + wv * R;
         const bool more = t + 1 < T;
         bool wave_on = false;
+        bool clean = false;
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             // ---- barrier before pass j: load j is waited for, counting the ring loads issued after
@@ -2238,14 +2248,31 @@ void k_search_pipe(Params p) {
                     // the wave's 8 rows of words: lanes 0..15 look at 16 bytes each
                     const uint4 qw = ((const uint4*)vb)[wv * 16 + (lane & 15)];
                     wave_any = __ballot((qw.x & qw.y & qw.z & qw.w) != 0xffffffffu) != 0;
+                    if (edge_ok) {
+                        // even lanes hold words 0 and 1 of a row, odd lanes words 2 and 3
+                        // (three ballots against scalar operands: nothing lane-dependent is kept across tiles)
+                        const unsigned long long off02 = __ballot((qw.x | qw.y) != 0u);
+                        const unsigned long long off1 = __ballot((qw.z | qw.w) != 0u) & 0x5555555555555555ull;
+                        const unsigned long long off3 = __ballot(qw.z != (uint32_t)edge_word || qw.w != (uint32_t)(edge_word >> 32)) & 0xaaaaaaaaaaaaaaaaull;
+                        clean = (off02 | off1 | off3) == 0;
+                    }
+                    if (clean) {
+                        // (a zero the compiler cannot see through: folded into the first matrix instruction of
+                        // each accumulator it would cost the in-place update of the others their registers)
+                        int zero;
+                        asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
 #pragma unroll
-                    for (int yy = 0; yy < R; ++yy) {
-                        const unsigned long long w = vb[(wv * R + yy) * 4 + g] >> (lane & 15);
-                        const uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
-                        acc[yy][0] = sbit_field(lo, 0) << 20;
-                        acc[yy][1] = sbit_field(lo, 16) << 20;
-                        acc[yy][2] = sbit_field(hi, 0) << 20;
-                        acc[yy][3] = sbit_field(hi, 16) << 20;
+                        for (int yy = 0; yy < R; ++yy) acc[yy] = v4i{zero, zero, zero, zero};
+                    } else {
+#pragma unroll
+                        for (int yy = 0; yy < R; ++yy) {
+                            const unsigned long long w = vb[(wv * R + yy) * 4 + g] >> (lane & 15);
+                            const uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
+                            acc[yy][0] = sbit_field(lo, 0) << 20;
+                            acc[yy][1] = sbit_field(lo, 16) << 20;
+                            acc[yy][2] = sbit_field(hi, 0) << 20;
+                            acc[yy][3] = sbit_field(hi, 16) << 20;
+                        }
                     }
                 } else {
                     int anyvalid = 0;
@@ -2283,6 +2310,12 @@ void k_search_pipe(Params p) {
             }
         }
 
+        if (clean) {
+            // windows beyond the right edge, as far below as a start value of -POISON would have put them
+            const int edge_add = wx + 48 >= ncx ? -(POISON << 8) : 0;
+#pragma unroll
+            for (int yy = 0; yy < R; ++yy) acc[yy][3] += edge_add;
+        }
         if (t == 0) STAMP_MID(36);
         // pricing, as in k_search_mfma
         double bc = INFINITY;
