@@ -721,9 +721,13 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
     }
     const int RS = PT > 0 ? CRIM_TILE + PT - 1 : CRIM_TILE + 2 * half;   // edge of the staged region
     constexpr int MS = CRIM_TILE + 2;                                    // edge of the staged mask
-    uint4* s_el = (uint4*)smem;
+    // Two planes of 8-byte records over the staged region (not one of 16-byte records): the confidence
+    // alone is what most tiles read, and consecutive doubles spread over every LDS bank where the
+    // confidence halves of 16-byte records use only half of them.
+    double* s_cf = (double*)smem;                   // confidence
+    uint2* s_gk = (uint2*)(s_cf + RS * RS);         // (4*|gradient|^2 << 10, packed gradient); fresh tiles only
     // (byte and 16-bit entries: at patch edge 9 the block then fits 10 KB, 16 waves per CU)
-    uint8_t* s_list = (uint8_t*)(s_el + RS * RS);   // tile-local pixel index, < 256
+    uint8_t* s_list = (uint8_t*)(s_gk + RS * RS);   // tile-local pixel index, < 256
     uint8_t* s_mask = s_list + CRIM_TILE * CRIM_TILE;
     const int* tl = p.tlist + (size_t)b * p.tcap;
     const int* tf = p.tfront + (size_t)b * p.tnx * p.tny;
@@ -753,12 +757,12 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
             {
                 const int e = 8 * i + 2 * ll;
                 const int row = e / (PT > 0 ? PT : 1), col = e - row * PT;
-                o.x = (row * RS + col) * 16;
+                o.x = (row * RS + col) * 8;
             }
             {
                 const int e = 8 * i + 2 * ll + 1;
                 const int row = e / (PT > 0 ? PT : 1), col = e - row * PT;
-                o.y = (row * RS + col) * 16;
+                o.y = (row * RS + col) * 8;
             }
             s_off[ll * NE + i] = o;
         }
@@ -839,19 +843,16 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
                     const int row = rb + k * rpp;
                     if (row < RS && scol < RS) {
                         const int gy2 = (int)(short)(gv[k] & 0xffff), gx2 = gv[k] >> 16;
-                        uint4 el;
-                        el.x = (uint32_t)__double2loint(cv[k]); el.y = (uint32_t)__double2hiint(cv[k]);
-                        el.z = (uint32_t)(gy2 * gy2 + gx2 * gx2) << 10;
-                        el.w = (uint32_t)gv[k];
-                        s_el[row * RS + scol] = el;
+                        s_cf[row * RS + scol] = cv[k];
+                        s_gk[row * RS + scol] = make_uint2((uint32_t)(gy2 * gy2 + gx2 * gx2) << 10, (uint32_t)gv[k]);
                     }
                 }
             } else {
-                // the confidence half of each record only
+                // the confidence plane only
 #pragma unroll
                 for (int k = 0; k < NRB; ++k) {
                     const int row = rb + k * rpp;
-                    if (row < RS && scol < RS) *(double*)(s_el + row * RS + scol) = cv[k];
+                    if (row < RS && scol < RS) s_cf[row * RS + scol] = cv[k];
                 }
             }
         }
@@ -874,8 +875,8 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
         }
         __syncthreads();
         if (ti == bx) STAMP_MID(6);
-        View<double> vconf; vconf.base = (const unsigned char*)s_el; vconf.pitch = RS; vconf.oy = ry0; vconf.ox = rx0; vconf.stride = 16;
-        View<int> vgrad; vgrad.base = (const unsigned char*)s_el + 12; vgrad.pitch = RS; vgrad.oy = ry0; vgrad.ox = rx0; vgrad.stride = 16;
+        View<double> vconf; vconf.base = (const unsigned char*)s_cf; vconf.pitch = RS; vconf.oy = ry0; vconf.ox = rx0; vconf.stride = 8;
+        View<int> vgrad; vgrad.base = (const unsigned char*)s_gk + 4; vgrad.pitch = RS; vgrad.oy = ry0; vgrad.ox = rx0; vgrad.stride = 8;
         for (int e = grp; e < n; e += 64 / PG) {
             const int pi = s_list[e];
             const int py = pi >> 4, px = pi & 15;
@@ -894,7 +895,7 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
                 const double dcached = dterm[fy * W + fx];
                 double cn;
                 if (PT > 0 && PG == 4 && inside) {
-                    const unsigned char* eb = (const unsigned char*)s_el + (py * RS + px) * 16;
+                    const unsigned char* eb = (const unsigned char*)s_cf + (py * RS + px) * 8;
                     double r0 = 0.0, r1 = 0.0;
                     auto block = [&](int i, bool first) {
                         const ushort2 o = s_off[l * NE + i];
@@ -910,7 +911,7 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
 #pragma unroll 5
                     for (int i = 0; i < NA; ++i) block(i, i == 0);
                     double t = leaf_sum();
-                    const double tl_ = *(const double*)(eb + ((PT - 1) * RS + (PT - 1)) * 16);
+                    const double tl_ = *(const double*)(eb + ((PT - 1) * RS + (PT - 1)) * 8);
                     if constexpr (NA < NE) {
 #pragma unroll 5
                         for (int i = NA; i < NE; ++i) block(i, i == NA);
@@ -928,18 +929,18 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
                 ev.data = dcached;
                 ev.prio = cn * dcached * (double)F;
             } else if (PT > 0 && PG == 4 && inside) {
-                const unsigned char* eb = (const unsigned char*)s_el + (py * RS + px) * 16;
+                const unsigned char* eb = (const unsigned char*)s_cf + (py * RS + px) * 8;
+                const unsigned char* gb = (const unsigned char*)s_gk + (py * RS + px) * 8;
                 double r0 = 0.0, r1 = 0.0;
                 unsigned best = 0;
                 const unsigned kb = 1023u - 2u * (unsigned)l;
                 auto block = [&](int i, bool first) {
                     const ushort2 o = s_off[l * NE + i];
-                    const uint4 a = *(const uint4*)(eb + o.x);
-                    const uint4 c = *(const uint4*)(eb + o.y);
-                    const double ca = __hiloint2double((int)a.y, (int)a.x);
-                    const double cc = __hiloint2double((int)c.y, (int)c.x);
+                    const double ca = *(const double*)(eb + o.x);
+                    const double cc = *(const double*)(eb + o.y);
+                    const unsigned az = *(const unsigned*)(gb + o.x), cz = *(const unsigned*)(gb + o.y);
                     if (first) { r0 = ca; r1 = cc; } else { r0 += ca; r1 += cc; }
-                    const unsigned ka = a.z + (kb - 8u * i), kc = c.z + (kb - 8u * i - 1u);
+                    const unsigned ka = az + (kb - 8u * i), kc = cz + (kb - 8u * i - 1u);
                     best = ka > best ? ka : best;
                     best = kc > best ? kc : best;
                 };
@@ -953,26 +954,27 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
                 for (int i = 0; i < NA; ++i) block(i, i == 0);
                 double t = leaf_sum();
                 constexpr int EL = PT * PT - 1;   // the one tail element: PT*PT = 1 (mod 8)
-                const uint4 tl_ = *(const uint4*)(eb + ((PT - 1) * RS + (PT - 1)) * 16);
+                const double tl_ = *(const double*)(eb + ((PT - 1) * RS + (PT - 1)) * 8);
+                const unsigned tlz = *(const unsigned*)(gb + ((PT - 1) * RS + (PT - 1)) * 8);
                 if constexpr (NA < NE) {
                     // second half of the split: its own leaf, then its tail, then the halves are added
 #pragma unroll 5
                     for (int i = NA; i < NE; ++i) block(i, i == NA);
                     double t2 = leaf_sum();
-                    t2 += __hiloint2double((int)tl_.y, (int)tl_.x);
+                    t2 += tl_;
                     t = t + t2;
                 } else {
-                    t += __hiloint2double((int)tl_.y, (int)tl_.x);
+                    t += tl_;
                 }
                 unsigned ob = (unsigned)dpp_i32<DPP_QUAD_XOR1>((int)best);
                 best = ob > best ? ob : best;
                 ob = (unsigned)dpp_i32<DPP_QUAD_XOR2>((int)best);
                 best = ob > best ? ob : best;
-                const unsigned kt = tl_.z + (1023u - (unsigned)EL);
+                const unsigned kt = tlz + (1023u - (unsigned)EL);
                 best = kt > best ? kt : best;
                 const int be = 1023 - (int)(best & 1023u);
                 const int brow = be / (PT > 0 ? PT : 1), bcol = be - brow * PT;
-                const int bpk = (int)((const uint4*)eb)[brow * RS + bcol].w;
+                const int bpk = (int)((const uint2*)gb)[brow * RS + bcol].y;
                 ev = finish_front_pixel(t / (double)p.psq, nb, F, bpk);
             } else {
                 ev = eval_front_pixel<(PT > 0 ? (PT * PT > 128 ? 1 : 0) : 3)>(p, vgrad, vconf, fy, fx, F, nb, l);
