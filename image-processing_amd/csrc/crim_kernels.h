@@ -29,6 +29,8 @@
 #define STAMP_BLOCK(which)                                                                  \
     do {                                                                                    \
         if (threadIdx.x == 0 && blockIdx.x < 4096) p.dbg[64 + 2 * blockIdx.x + (which)] = wall_clock64(); \
+        /* the shader clock beside the wall clock for one block: their ratio is the clock rate under load */ \
+        if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2 + 5) p.dbg[56 + (which)] = clock64(); \
     } while (0)
 #else
 #define STAMP(slot) do {} while (0)

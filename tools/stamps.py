@@ -32,6 +32,8 @@ for it in range(20):
 for k, v in acc.items():
     print(k, "mean ns per phase:", np.mean(v, axis=0).astype(int).tolist(), "total", int(np.mean(np.sum(v, axis=1))))
 st = np.zeros(64, np.int64); lib.crim_debug_stamps(eng._h, st.ctypes.data)
+if st[57] > st[56] and st[38] > st[32]:
+    print("search block in the middle of the grid: %d shader cycles in %.2f us -> %.2f GHz" % (st[57] - st[56], (st[38] - st[32]) * 0.01, (st[57] - st[56]) / ((st[38] - st[32]) * 10.0)))
 if st[51]:
     print("search: priced windows %d in %d blocks -> %.2f per block" % (st[50], st[51], st[50] / st[51]))
 if hasattr(lib, "crim_debug_block_stamps"):
