@@ -296,8 +296,10 @@ static void launch_compact(const Params& p, hipStream_t s) {
 
 static size_t priority_lds_bytes(const Params& p) {
     const size_t rs = CRIM_TILE + 2 * p.half;
-    // records, front list (bytes), mask, per-lane offset table (4 x 28 pairs of 16-bit offsets at most), alignment slack
-    return rs * rs * 16 + CRIM_TILE * CRIM_TILE + (CRIM_TILE + 2) * (CRIM_TILE + 2) + 4 * 28 * 4 + 8;
+    // two 8-byte planes, front list (bytes), mask, per-lane offset table (4 lanes x P*P/8 pairs of 16-bit offsets
+    // on the fast path, patch edges up to 15), alignment slack.  At patch edge 9 this is just under 10 KB.
+    const size_t table = 4 * (size_t)(p.P <= 15 ? (p.P * p.P) / 8 + 1 : 1) * 4;
+    return rs * rs * 16 + CRIM_TILE * CRIM_TILE + (CRIM_TILE + 2) * (CRIM_TILE + 2) + table + 8;
 }
 
 static void launch_update(const Params& p, hipStream_t s) {
