@@ -117,6 +117,23 @@ def test_wide_image_spans_several_search_tiles():
     assert_same_as_oracle(img, m, 7)
 
 
+@pytest.mark.parametrize("p,W", [(9, 247), (9, 248), (9, 255), (9, 256), (9, 263), (9, 264), (9, 271),
+                                 (9, 496), (9, 503), (9, 504), (9, 512), (9, 519), (9, 520),
+                                 (5, 244), (5, 259), (15, 254), (15, 270), (15, 526)])
+def test_search_waves_without_inadmissible_windows(p, W):
+    # A search wave whose 8 origin rows hold no inadmissible window left of the image's right edge
+    # starts its accumulators from zero and removes the edge windows afterwards -- only when the edge
+    # cuts at most the last of a lane's four windows, i.e. when the last 256-origin tile of a row
+    # holds 240..256 admissible columns.  Widths on both sides of those limits, one small hole
+    # (most waves have nothing to exclude, a few do), grey and colour.
+    H = 72
+    for colour in (False, True):
+        img = crim_synth.xray_like(H, W, 7000 + W + p, colour=colour)
+        m = np.zeros((H, W), np.uint8)
+        m[30:30 + p + 2, W // 3:W // 3 + p + 3] = 1
+        assert_same_as_oracle(img, m, p)
+
+
 @pytest.mark.parametrize("p,tiles,H,W,border,colour", [
     (9, 8, 300, 200, False, False), (5, 3, 200, 90, True, False), (13, 8, 270, 300, False, False),
     (9, 2, 140, 600, True, False), (7, 8, 33, 64, False, False), (15, 4, 210, 120, True, False),
