@@ -3,7 +3,7 @@
 # -ffp-contract=off: the fp64 confidence / priority / cost arithmetic must not be fused.
 set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
-OUT="$HERE/../lib"
+OUT="${CRIM_LIB_OUT:-$HERE/../lib}"   # CRIM_LIB_OUT: alternative output directory (diagnostic builds)
 mkdir -p "$OUT"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 "$HIPCC" -O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -shared -std=c++17 \

@@ -8,6 +8,11 @@
 #define CRIM_PMAX CRIM_MAX_PATCH
 #define CRIM_NDMAX ((CRIM_PMAX + 6) / 4)
 #define CRIM_NPL 7            // search byte planes per image
+// 16x16 tiles that can hold a front pixel whose data term an iteration changes: the filled patch grown
+// by the patch half-width plus one spans 2 P + 1 <= 33 pixels for patch edges up to 16, i.e. at most
+// 3 tiles each way
+#define CRIM_NEAR_SPAN 3
+#define CRIM_NEAR_TILES (CRIM_NEAR_SPAN * CRIM_NEAR_SPAN)
 
 // Matrix-core search tiling: a 256-thread block scores MS_W x MS_ROWS window origins; each of its
 // 4 waves owns MS_R consecutive origin rows.  Patch edges up to MS_PMAX.
@@ -38,7 +43,8 @@ struct ImgState {
     int stalled;     // an iteration filled nothing while pixels remained
     int bound;       // running upper bound on floor(best cost) for search pruning
     int rebuilds;    // times k_update rebuilt a tile list that had outgrown its capacity
-    int pad[5];
+    int tlsel;       // which of the image's two tile-list buffers is current
+    int pad[4];
 };
 
 // Best front pixel of one priority tile.
@@ -64,12 +70,16 @@ struct Desc {
     int ncy, ncx;        // candidate grid: H-ph+1, W-pw+1
     int soff;            // S_reference = S_centred + soff
     int soff2;           // S_reference = soff2 - (256*sum k*h + 2*cross + sum k*l), digits of 24576 - Q
-    int pad2;
+    int cur;             // loop state as the selection saw it: current confidence buffer, ...
     int rowmask;         // bit i set: template row i has at least one known pixel
     int chmask;          // bit c set: k * (Lab_c - 128) is nonzero somewhere in the template
-    int pad1;
+    int nfill;           // masked pixels of the target patch: what this iteration fills
     double cnew;         // updated confidence at the target pixel
     double ty, tx;       // patch centre as the reference computes it
+    int iter, remaining; // ... iterations done and masked pixels left before this iteration,
+    int tlsel;           // ... current tile-list buffer,
+    unsigned tcount;     // ... and its length
+    long long t_select;  // 100 MHz wall clock when the selection finished (the search starts here)
     // Templates as byte planes, zero padded: kflat = 1 - mask, tflat = k * (Lab - 128).
     uint8_t kflat[CRIM_PMAX * CRIM_PMAX];
     int8_t tflat[3][CRIM_PMAX * CRIM_PMAX];
@@ -100,7 +110,11 @@ struct Params {
     int mtiles, mchunks; // pipelined matrix-core search: rows of tiles per block, blocks per column of tiles
     int pipe_t, pipe_min_blocks; // host side: most rows of tiles per block (0 = plain kernel), launch size below which fewer are used
     int nparts;   // > 0: split search, k_update reduces xchg[0..nparts) instead of the partial list
-    int pgrid;    // priority-scan blocks per image
+    int pgrid;    // priority slots per image: one per wave of the priority stage
+    int fused;    // host side: an iteration is the search launch (which also selects) and ONE launch that
+                  // updates the image and evaluates the next iteration's priorities (k_step)
+    int nfar;     // k_step: waves per image that walk the tile list (slots CRIM_NEAR_TILES ..)
+    int plds;     // bytes of LDS one priority wave works in
     int generic;  // use the unspecialised search kernel
     int dot4;     // use the vector dot-product search kernel instead of the matrix-core one
     int chroma;   // some uploaded image is not grey: the matrix-core search stages all five planes
@@ -118,11 +132,13 @@ struct Params {
     Desc* desc;
     int tcap;          // capacity of one image's tile list (twice the tile count)
     int* tfront;       // [B][tny*tnx] front pixels per 16x16 tile
-    int* tlist;        // [B][tcap] tiles the priority stage visits
+    int* tlist;        // [B][2][tcap] tiles the priority stage visits (two buffers: a rebuild that runs beside
+                       // readers of the list writes the other one, ImgState::tlsel names the current one)
     PEntry* plist;     // [B][pgrid]
     SEntry* slist;     // [B][snx*sny]
     SEntry* xchg;      // [64] per-part best window of a split search
     crim_iter_rec* trace;  // [B][trace_cap]
+    float* stime;          // [B][trace_cap] microseconds from the end of the selection to the start of the update
     long long* dbg;        // diagnostic stamps (only written by -DCRIM_STAMPS builds)
     const uint16_t* gamma_tab;
     const uint16_t* cbrt_tab;
