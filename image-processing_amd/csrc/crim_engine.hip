@@ -323,6 +323,22 @@ static void launch_priority(const Params& p, hipStream_t s) {
     }
 }
 
+// The launch that follows the search in the two-launch iteration (k_step: update + the next iteration's
+// priority stage); only patch edges with a pipelined search instance reach it.
+static void launch_step(const Params& p, hipStream_t s) {
+    const dim3 grid((unsigned)p.kblocks * p.B), block(256);
+    const size_t lds = (size_t)4 * p.plds;
+    switch (p.P) {
+        case 3: hipLaunchKernelGGL(k_step<3>, grid, block, lds, s, p); break;
+        case 5: hipLaunchKernelGGL(k_step<5>, grid, block, lds, s, p); break;
+        case 7: hipLaunchKernelGGL(k_step<7>, grid, block, lds, s, p); break;
+        case 9: hipLaunchKernelGGL(k_step<9>, grid, block, lds, s, p); break;
+        case 11: hipLaunchKernelGGL(k_step<11>, grid, block, lds, s, p); break;
+        case 13: hipLaunchKernelGGL(k_step<13>, grid, block, lds, s, p); break;
+        default: hipLaunchKernelGGL(k_step<15>, grid, block, lds, s, p); break;
+    }
+}
+
 // Iterations between two ordered rebuilds of the tile list (stale entries only cost a skipped
 // lookup; a rebuild walks every tile of the image, so large images rebuild less often).
 static int compact_period(const Params& p) { return p.tnx * p.tny > 1024 ? 64 : 16; }
@@ -340,12 +356,22 @@ static void launch_iteration(const Params& p, hipStream_t s, hipEvent_t ev0 = nu
     launch_update(p, s);
 }
 
+// The two-launch iteration (p.fused): the search launch, which also selects the target, then k_step.
+// The priority stage of the FIRST iteration of a sequence is launch_priority, issued once by the caller
+// (it is idempotent: repeating it for an iteration whose priorities k_step has already worked out
+// rewrites the same values).
+static void launch_iteration_fused(const Params& p, hipStream_t s) {
+    launch_search(p, s, 0, -1, true);
+    launch_step(p, s);
+}
+
 static int build_graph(Lane& ln, int iters, GraphSet* out) {
     hipGraph_t graph = nullptr;
     HIP_TRY(hipStreamBeginCapture(ln.stream, hipStreamCaptureModeThreadLocal));
     const int period = compact_period(ln.prm);
     for (int i = 0; i < iters; ++i) {
-        launch_iteration(ln.prm, ln.stream);
+        if (ln.prm.fused) launch_iteration_fused(ln.prm, ln.stream);
+        else launch_iteration(ln.prm, ln.stream);
         if ((i + 1) % period == 0) launch_compact(ln.prm, ln.stream);
     }
     HIP_TRY(hipStreamEndCapture(ln.stream, &graph));
@@ -403,6 +429,18 @@ static void init_geometry(Params& p, int batch, int H, int W, int patch_size, un
     if (const char* e = getenv("CRIM_SELECT_IN_SEARCH")) p.selsearch = atoi(e) ? 1 : 0;
     if (flags & (CRIM_FLAG_PROFILE | CRIM_FLAG_PROFILE_SOLO)) p.selsearch = 0;   // the bracketed launch is the search alone
     if (p.selsearch && !getenv("CRIM_PGRID")) p.pgrid = std::min(p.pgrid, 1024);   // every search block reads all of them
+    p.plds = (int)((priority_lds_bytes(p) + 15) & ~(size_t)15);
+    // Two launches per iteration where the search launch selects: the update and the next iteration's
+    // priority stage share one launch (k_step).  Its priority slots: one per near tile, then one per
+    // far wave (a multiple of 4: four waves per block), at most 1024 in all (what a search block reads
+    // in one batch of loads).
+    p.fused = (search_selects(p) && !(flags & (CRIM_FLAG_EAGER | CRIM_FLAG_PROFILE | CRIM_FLAG_PROFILE_SOLO))) ? 1 : 0;
+    if (const char* e = getenv("CRIM_FUSED")) p.fused = (p.fused && atoi(e)) ? 1 : 0;
+    if (p.fused) {
+        p.nfar = std::max(4, std::min(p.pgrid, 1024 - CRIM_NEAR_TILES - 3) / 4 * 4);
+        p.pgrid = CRIM_NEAR_TILES + p.nfar;
+        p.kblocks = 1 + (CRIM_NEAR_TILES + 3) / 4 + p.nfar / 4;
+    }
 }
 
 extern "C" int crim_device_count(void) {
@@ -435,7 +473,7 @@ extern "C" void crim_destroy(crim_t* h) {
         if (e) (void)hipEventDestroy(e);
     Params& p = h->prm;
     void* bufs[] = {p.bgr, p.planes, p.mask, p.grey, p.grad, p.conf, p.dterm, p.invalid, p.invbits, p.tfront, p.tlist, p.st,
-                    p.desc, p.plist, p.slist, p.xchg, p.trace, p.dbg, h->d_gamma, h->d_cbrt, h->d_peek};
+                    p.desc, p.plist, p.slist, p.xchg, p.trace, p.stime, p.dbg, h->d_gamma, h->d_cbrt, h->d_peek};
     for (void* q : bufs)
         if (q) (void)hipFree(q);
     if (h->h_state) (void)hipHostFree(h->h_state);
@@ -482,7 +520,7 @@ extern "C" int crim_create_batch(int batch, int H, int W, int patch_size, int de
     alloc((void**)&p.invalid, Bz * H * p.Wi);
     alloc((void**)&p.invbits, Bz * H * p.Wb * sizeof(unsigned long long));
     alloc((void**)&p.tfront, Bz * p.tnx * p.tny * sizeof(int));
-    alloc((void**)&p.tlist, Bz * p.tcap * sizeof(int));
+    alloc((void**)&p.tlist, Bz * 2 * p.tcap * sizeof(int));
     alloc((void**)&p.st, Bz * sizeof(ImgState));
     alloc((void**)&p.desc, Bz * sizeof(Desc));
     alloc((void**)&p.plist, Bz * p.pgrid * sizeof(PEntry));
@@ -499,6 +537,7 @@ extern "C" int crim_create_batch(int batch, int H, int W, int patch_size, int de
     if (e == hipSuccess) e = hipMemset(p.invalid, 1, Bz * H * p.Wi);
     if (e == hipSuccess) e = hipMemset(p.invbits, 0xff, Bz * H * p.Wb * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(p.st, 0, Bz * sizeof(ImgState));
+    if (e == hipSuccess) e = hipMemset(p.tlist, 0, Bz * 2 * p.tcap * sizeof(int));
     if (e == hipSuccess) e = hipMemset(p.dbg, 0, kDbgSlots * sizeof(long long));
     if (e == hipSuccess) e = hipMemset(p.desc, 0, Bz * sizeof(Desc));
     if (e != hipSuccess) {
@@ -683,8 +722,11 @@ static int prepare(crim_engine* h) {
     for (int i = 0; i < p.B; ++i) q.chroma |= h->h_state[i].chroma ? 1 : 0;
     if (!(h->flags & CRIM_FLAG_NO_TRACE) && (need > p.trace_cap || !p.trace)) {
         if (p.trace) HIP_TRY(hipFree(p.trace));
+        if (p.stime) HIP_TRY(hipFree(p.stime));
         q.trace = nullptr;
         p.trace = nullptr;
+        q.stime = nullptr;
+        p.stime = nullptr;
         q.trace_cap = 0;
         p.trace_cap = 0;
         const hipError_t te = hipMalloc((void**)&q.trace, (size_t)p.B * need * sizeof(crim_iter_rec));
@@ -696,6 +738,7 @@ static int prepare(crim_engine* h) {
                         need, p.B, hipGetErrorString(te));
         }
         q.trace_cap = need;
+        if (hipMalloc((void**)&q.stime, (size_t)p.B * need * sizeof(float)) != hipSuccess) q.stime = nullptr;   // optional
     }
     const bool changed = memcmp(&q, &p, sizeof(Params)) != 0;
     p = q;
@@ -922,6 +965,8 @@ extern "C" int crim_run(crim_t* h, long max_iters, long* iters_done, long* remai
                 }
                 ln.done += need;
             } else {
+                // two-launch iterations: the sequence starts with the priority stage of its first iteration
+                if (lp.fused) launch_priority(lp, ln.stream);
                 long left = need;
                 for (auto& g : ln.graphs)
                     while (left >= g.iters) {
@@ -1033,6 +1078,21 @@ extern "C" int crim_trace(crim_t* h, int index, crim_iter_rec* buf, long cap, lo
     return CRIM_OK;
 }
 
+extern "C" int crim_search_times(crim_t* h, int index, float* us_out, long cap, long* n) {
+    if (!h || !n) return fail(CRIM_ERR_ARG, "crim_search_times: null argument");
+    const Params& p = h->prm;
+    if (index < 0 || index >= p.B) return fail(CRIM_ERR_ARG, "crim_search_times: index %d of %d", index, p.B);
+    long iters = 0;
+    const int rc = crim_iterations(h, index, &iters);
+    if (rc) return rc;
+    const long have = p.stime ? std::min(iters, p.trace_cap) : 0;
+    *n = have;
+    const long take = std::min(have, cap);
+    if (us_out && take > 0)
+        HIP_TRY(hipMemcpy(us_out, p.stime + (size_t)index * p.trace_cap, (size_t)take * sizeof(float), hipMemcpyDeviceToHost));
+    return CRIM_OK;
+}
+
 extern "C" int crim_profile(crim_t* h, double* search_ms, long* search_launches, double* evals) {
     if (!h) return fail(CRIM_ERR_ARG, "crim_profile: null handle");
     if (!(h->flags & CRIM_FLAG_PROFILE)) return fail(CRIM_ERR_STATE, "crim_profile: engine was not created with CRIM_FLAG_PROFILE");
@@ -1087,11 +1147,12 @@ extern "C" int crim_debug_fill_tile_list(crim_t* h, int index) {
     ImgState st;
     HIP_TRY(hipMemcpy(&st, p.st + index, sizeof(st), hipMemcpyDeviceToHost));
     std::vector<int> tl((size_t)p.tcap);
-    HIP_TRY(hipMemcpy(tl.data(), p.tlist + (size_t)index * p.tcap, tl.size() * sizeof(int), hipMemcpyDeviceToHost));
+    int* d_tl = p.tlist + ((size_t)index * 2 + st.tlsel) * p.tcap;
+    HIP_TRY(hipMemcpy(tl.data(), d_tl, tl.size() * sizeof(int), hipMemcpyDeviceToHost));
     if (st.tcount == 0 || st.tcount > (unsigned)p.tcap) return fail(CRIM_ERR_STATE, "crim_debug_fill_tile_list: list holds %u entries", st.tcount);
     for (int i = (int)st.tcount; i < p.tcap; ++i) tl[i] = tl[0];
     st.tcount = (unsigned)p.tcap;
-    HIP_TRY(hipMemcpy(p.tlist + (size_t)index * p.tcap, tl.data(), tl.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_tl, tl.data(), tl.size() * sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(p.st + index, &st, sizeof(st), hipMemcpyHostToDevice));
     return CRIM_OK;
 }
@@ -1220,7 +1281,7 @@ extern "C" int crim_inpaint_noalloc(int H, int W, int patch_size, int device, co
     c.take(&p.invalid, invalid_bytes);
     c.take(&p.invbits, invbits_bytes);
     c.take(&p.tfront, (size_t)p.tnx * p.tny * sizeof(int));
-    c.take(&p.tlist, (size_t)p.tcap * sizeof(int));
+    c.take(&p.tlist, (size_t)2 * p.tcap * sizeof(int));
     c.take(&p.st, sizeof(ImgState));
     c.take(&p.desc, sizeof(Desc));
     c.take(&p.plist, (size_t)p.pgrid * sizeof(PEntry));
@@ -1244,7 +1305,7 @@ extern "C" int crim_inpaint_noalloc(int H, int W, int patch_size, int device, co
     HIP_TRY(hipMemsetAsync(p.st, 0, sizeof(ImgState), s));
     HIP_TRY(hipMemsetAsync(p.desc, 0, sizeof(Desc), s));
     HIP_TRY(hipMemsetAsync(p.tfront, 0, (size_t)p.tnx * p.tny * sizeof(int), s));
-    HIP_TRY(hipMemsetAsync(p.tlist, 0, (size_t)p.tcap * sizeof(int), s));
+    HIP_TRY(hipMemsetAsync(p.tlist, 0, (size_t)2 * p.tcap * sizeof(int), s));
     HIP_TRY(hipMemcpyAsync(d_gamma, t.gamma, sizeof(t.gamma), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d_cbrt, t.cbrt_, sizeof(t.cbrt_), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(p.bgr, d_bgr, HW * 3, hipMemcpyDeviceToDevice, s));
@@ -1270,9 +1331,11 @@ extern "C" int crim_inpaint_noalloc(int H, int W, int patch_size, int device, co
             need = std::max(need, (long)((double)st.remaining * (double)last / (double)filled));
         need = std::min(need, 4096L);
         prev_remaining = st.remaining;
+        if (p.fused) launch_priority(p, s);
         for (long i = 0; i < need; ++i) {
             if ((done + i) > 0 && (done + i) % compact_period(p) == 0) launch_compact(p, s);
-            launch_iteration(p, s);
+            if (p.fused) launch_iteration_fused(p, s);
+            else launch_iteration(p, s);
         }
         done += need;
         last = need;

@@ -569,7 +569,7 @@ __global__ __launch_bounds__(256) void k_init_fields(Params p, int first) {
     if (threadIdx.x == 0) {
         const int tile = blockIdx.y * p.tnx + blockIdx.x;
         p.tfront[(size_t)b * p.tnx * p.tny + tile] = cnt;
-        if (cnt) p.tlist[(size_t)b * p.tcap + atomicAdd(&p.st[b].tcount, 1u)] = tile;
+        if (cnt) p.tlist[(size_t)b * 2 * p.tcap + atomicAdd(&p.st[b].tcount, 1u)] = tile;   // buffer 0 (tlsel = 0)
     }
 }
 
@@ -580,7 +580,7 @@ __global__ void k_init_state(Params p, int first, int count) {
     s->iter = 0; s->live = 1; s->cur = 0; s->remaining = 0;
     s->tcount = 0; s->chroma = 0;
     s->pcount = 0; s->scount = 0; s->stalled = 0; s->bound = 0x7fffffff;
-    s->rebuilds = 0;
+    s->rebuilds = 0; s->tlsel = 0;
     p.desc[first + i].live = 0;
 }
 
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(1024) void k_tiles(Params p) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nt = p.tnx * p.tny;
     const int* tf = p.tfront + (size_t)b * nt;
-    int* tl = p.tlist + (size_t)b * p.tcap;
+    int* tl = p.tlist + ((size_t)b * 2 + st->tlsel) * p.tcap;
     unsigned base = 0;
     for (int t0 = 0; t0 < nt; t0 += 4096) {
         const int t = t0 + 4 * tid;
@@ -664,6 +664,139 @@ __device__ __forceinline__ FrontEval finish_front_pixel(double cnew, const int n
     return out;
 }
 
+// Evaluates the n front pixels a priority wave has listed for the tile at (ty0, tx0) from the fields it
+// staged in LDS (s_cf: confidence over the tile grown by the patch half-width, RS x RS; s_gk: gradient
+// key and packed gradient over the same region, fresh tiles only; s_mask: mask over the tile grown by
+// one pixel; s_list: tile-local indices of the front pixels; s_off: the per-lane offset table of the
+// fast path).  Groups of PG lanes take one pixel each: new confidence (written to cnxt), data term
+// (computed and written to dterm when `fresh`, else read from dterm) and priority; lane 0 of each group
+// keeps the best (priority, position) it has seen in bestP / bestI.
+template <int PT>
+__device__ __forceinline__ void prio_eval_tile(const Params& p, const double* s_cf, const uint2* s_gk,
+                                               const uint8_t* s_list, const uint8_t* s_mask, const ushort2* s_off,
+                                               const int RS, const int ty0, const int tx0, const int n,
+                                               const bool fresh, double* dterm, double* cnxt, const int grp,
+                                               const int l, double& bestP, int& bestI) {
+    constexpr int MS = CRIM_TILE + 2;
+    constexpr int NE = PT > 0 ? (PT * PT) / 8 : 1;
+    // blocks of 8 in the first half of the pairwise split (all of them when there is no split)
+    constexpr int NA = PT * PT <= 128 ? NE : ((PT * PT / 2) - (PT * PT / 2) % 8) / 8;
+    static_assert(PT * PT <= 256, "one split level: both halves are leaves");
+    const int H = p.H, W = p.W, half = p.half;
+    const int ry0 = ty0 - half, rx0 = tx0 - half;
+    View<double> vconf; vconf.base = (const unsigned char*)s_cf; vconf.pitch = RS; vconf.oy = ry0; vconf.ox = rx0; vconf.stride = 8;
+    View<int> vgrad; vgrad.base = (const unsigned char*)s_gk + 4; vgrad.pitch = RS; vgrad.oy = ry0; vgrad.ox = rx0; vgrad.stride = 8;
+    for (int e = grp; e < n; e += 64 / PG) {
+        const int pi = s_list[e];
+        const int py = pi >> 4, px = pi & 15;
+        const int fy = ty0 + py, fx = tx0 + px;
+        const uint8_t* m0 = s_mask + py * MS + px;
+        int nb[9];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) nb[a * 3 + c] = m0[a * MS + c];
+        const int F = front_from_nb(nb);
+        FrontEval ev;
+        const bool inside = fy >= half && fy + half < H && fx >= half && fx + half < W;
+        if (!fresh) {
+            // cached data term (requested before the sum, used after it)
+            const double dcached = dterm[fy * W + fx];
+            double cn;
+            if (PT > 0 && PG == 4 && inside) {
+                const unsigned char* eb = (const unsigned char*)s_cf + (py * RS + px) * 8;
+                double r0 = 0.0, r1 = 0.0;
+                auto block = [&](int i, bool first) {
+                    const ushort2 o = s_off[l * NE + i];
+                    const double ca = *(const double*)(eb + o.x);
+                    const double cc = *(const double*)(eb + o.y);
+                    if (first) { r0 = ca; r1 = cc; } else { r0 += ca; r1 += cc; }
+                };
+                auto leaf_sum = [&]() {
+                    double t = r0 + r1;
+                    t = t + dpp_f64<DPP_QUAD_XOR1>(t);
+                    return t + dpp_f64<DPP_QUAD_XOR2>(t);
+                };
+#pragma unroll 5
+                for (int i = 0; i < NA; ++i) block(i, i == 0);
+                double t = leaf_sum();
+                const double tl_ = *(const double*)(eb + ((PT - 1) * RS + (PT - 1)) * 8);
+                if constexpr (NA < NE) {
+#pragma unroll 5
+                    for (int i = NA; i < NE; ++i) block(i, i == NA);
+                    double t2 = leaf_sum();
+                    t2 += tl_;
+                    t = t + t2;
+                } else {
+                    t += tl_;
+                }
+                cn = t / (double)p.psq;
+            } else {
+                cn = front_confidence<(PT > 0 ? (PT * PT > 128 ? 1 : 0) : 3)>(p, vconf, fy, fx, l);
+            }
+            ev.cnew = cn;
+            ev.data = dcached;
+            ev.prio = cn * dcached * (double)F;
+        } else if (PT > 0 && PG == 4 && inside) {
+            const unsigned char* eb = (const unsigned char*)s_cf + (py * RS + px) * 8;
+            const unsigned char* gb = (const unsigned char*)s_gk + (py * RS + px) * 8;
+            double r0 = 0.0, r1 = 0.0;
+            unsigned best = 0;
+            const unsigned kb = 1023u - 2u * (unsigned)l;
+            auto block = [&](int i, bool first) {
+                const ushort2 o = s_off[l * NE + i];
+                const double ca = *(const double*)(eb + o.x);
+                const double cc = *(const double*)(eb + o.y);
+                const unsigned az = *(const unsigned*)(gb + o.x), cz = *(const unsigned*)(gb + o.y);
+                if (first) { r0 = ca; r1 = cc; } else { r0 += ca; r1 += cc; }
+                const unsigned ka = az + (kb - 8u * i), kc = cz + (kb - 8u * i - 1u);
+                best = ka > best ? ka : best;
+                best = kc > best ? kc : best;
+            };
+            // the four lanes' accumulator pairs combined in NumPy's tree order
+            auto leaf_sum = [&]() {
+                double t = r0 + r1;
+                t = t + dpp_f64<DPP_QUAD_XOR1>(t);
+                return t + dpp_f64<DPP_QUAD_XOR2>(t);
+            };
+#pragma unroll 5
+            for (int i = 0; i < NA; ++i) block(i, i == 0);
+            double t = leaf_sum();
+            constexpr int EL = PT * PT - 1;   // the one tail element: PT*PT = 1 (mod 8)
+            const double tl_ = *(const double*)(eb + ((PT - 1) * RS + (PT - 1)) * 8);
+            const unsigned tlz = *(const unsigned*)(gb + ((PT - 1) * RS + (PT - 1)) * 8);
+            if constexpr (NA < NE) {
+                // second half of the split: its own leaf, then its tail, then the halves are added
+#pragma unroll 5
+                for (int i = NA; i < NE; ++i) block(i, i == NA);
+                double t2 = leaf_sum();
+                t2 += tl_;
+                t = t + t2;
+            } else {
+                t += tl_;
+            }
+            unsigned ob = (unsigned)dpp_i32<DPP_QUAD_XOR1>((int)best);
+            best = ob > best ? ob : best;
+            ob = (unsigned)dpp_i32<DPP_QUAD_XOR2>((int)best);
+            best = ob > best ? ob : best;
+            const unsigned kt = tlz + (1023u - (unsigned)EL);
+            best = kt > best ? kt : best;
+            const int be = 1023 - (int)(best & 1023u);
+            const int brow = be / (PT > 0 ? PT : 1), bcol = be - brow * PT;
+            const int bpk = (int)((const uint2*)gb)[brow * RS + bcol].y;
+            ev = finish_front_pixel(t / (double)p.psq, nb, F, bpk);
+        } else {
+            ev = eval_front_pixel<(PT > 0 ? (PT * PT > 128 ? 1 : 0) : 3)>(p, vgrad, vconf, fy, fx, F, nb, l);
+        }
+        if (l == 0) {
+            const int pos = fy * W + fx;
+            cnxt[pos] = ev.cnew;
+            if (fresh) dterm[pos] = ev.data;
+            if (better_prio(ev.prio, pos, bestP, bestI)) { bestP = ev.prio; bestI = pos; }
+        }
+    }
+}
+
 // grid (pgrid, B), one wave per block; block g of image b walks entries g, g + pgrid, ... of
 // that image's tile list.  Per tile: the confidence and gradient fields of the tile grown by
 // the patch half-width (one 16-byte record per pixel: confidence, 4*|gradient|^2 << 10, packed
@@ -691,7 +824,7 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
     STAMP_MID(0);
     // the first list entry is requested together with the loop state (the list's capacity exceeds
     // the waves per image, so the read is in bounds; it is used only when bx < tcount)
-    const int tile_first = p.tlist[(size_t)b * p.tcap + bx];
+    const int tile_first = p.tlist[((size_t)b * 2 + st->tlsel) * p.tcap + bx];
     const int live = st->live;
     // (k_update rebuilds a list that outgrew its capacity before this kernel runs again; the clamp
     // only keeps a reader inside the list whatever the count says)
@@ -731,7 +864,7 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
     // (byte and 16-bit entries: at patch edge 9 the block then fits 10 KB, 16 waves per CU)
     uint8_t* s_list = (uint8_t*)(s_gk + RS * RS);   // tile-local pixel index, < 256
     uint8_t* s_mask = s_list + CRIM_TILE * CRIM_TILE;
-    const int* tl = p.tlist + (size_t)b * p.tcap;
+    const int* tl = p.tlist + ((size_t)b * 2 + st->tlsel) * p.tcap;
     const int* tf = p.tfront + (size_t)b * p.tnx * p.tny;
     const double* ccur = p.conf + ((size_t)b * 2 + cur) * HW;
     double* cnxt = p.conf + ((size_t)b * 2 + (cur ^ 1)) * HW;
@@ -745,9 +878,6 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
     // per-lane-of-group table of record offsets (LDS, not registers: the registers buy a fourth
     // wave per SIMD): s_off[l][2i + k] = byte offset of flattened element 8i + 2l + k
     constexpr int NE = PT > 0 ? (PT * PT) / 8 : 1;
-    // blocks of 8 in the first half of the pairwise split (all of them when there is no split)
-    constexpr int NA = PT * PT <= 128 ? NE : ((PT * PT / 2) - (PT * PT / 2) % 8) / 8;
-    static_assert(PT * PT <= 256, "one split level: both halves are leaves");
     static_assert(CRIM_TILE * CRIM_TILE <= 256, "tile-local pixel indices are bytes");
     // (an offset from the LDS base, not a pointer rounded up through an integer: that would make the
     // table's accesses generic-address loads, which wait for every outstanding global access)
@@ -877,117 +1007,8 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
         }
         __syncthreads();
         if (ti == bx) STAMP_MID(6);
-        View<double> vconf; vconf.base = (const unsigned char*)s_cf; vconf.pitch = RS; vconf.oy = ry0; vconf.ox = rx0; vconf.stride = 8;
-        View<int> vgrad; vgrad.base = (const unsigned char*)s_gk + 4; vgrad.pitch = RS; vgrad.oy = ry0; vgrad.ox = rx0; vgrad.stride = 8;
-        for (int e = grp; e < n; e += 64 / PG) {
-            const int pi = s_list[e];
-            const int py = pi >> 4, px = pi & 15;
-            const int fy = ty0 + py, fx = tx0 + px;
-            const uint8_t* m0 = s_mask + py * MS + px;
-            int nb[9];
-#pragma unroll
-            for (int a = 0; a < 3; ++a)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) nb[a * 3 + c] = m0[a * MS + c];
-            const int F = front_from_nb(nb);
-            FrontEval ev;
-            const bool inside = fy >= half && fy + half < H && fx >= half && fx + half < W;
-            if (!fresh) {
-                // cached data term (requested before the sum, used after it)
-                const double dcached = dterm[fy * W + fx];
-                double cn;
-                if (PT > 0 && PG == 4 && inside) {
-                    const unsigned char* eb = (const unsigned char*)s_cf + (py * RS + px) * 8;
-                    double r0 = 0.0, r1 = 0.0;
-                    auto block = [&](int i, bool first) {
-                        const ushort2 o = s_off[l * NE + i];
-                        const double ca = *(const double*)(eb + o.x);
-                        const double cc = *(const double*)(eb + o.y);
-                        if (first) { r0 = ca; r1 = cc; } else { r0 += ca; r1 += cc; }
-                    };
-                    auto leaf_sum = [&]() {
-                        double t = r0 + r1;
-                        t = t + dpp_f64<DPP_QUAD_XOR1>(t);
-                        return t + dpp_f64<DPP_QUAD_XOR2>(t);
-                    };
-#pragma unroll 5
-                    for (int i = 0; i < NA; ++i) block(i, i == 0);
-                    double t = leaf_sum();
-                    const double tl_ = *(const double*)(eb + ((PT - 1) * RS + (PT - 1)) * 8);
-                    if constexpr (NA < NE) {
-#pragma unroll 5
-                        for (int i = NA; i < NE; ++i) block(i, i == NA);
-                        double t2 = leaf_sum();
-                        t2 += tl_;
-                        t = t + t2;
-                    } else {
-                        t += tl_;
-                    }
-                    cn = t / (double)p.psq;
-                } else {
-                    cn = front_confidence<(PT > 0 ? (PT * PT > 128 ? 1 : 0) : 3)>(p, vconf, fy, fx, l);
-                }
-                ev.cnew = cn;
-                ev.data = dcached;
-                ev.prio = cn * dcached * (double)F;
-            } else if (PT > 0 && PG == 4 && inside) {
-                const unsigned char* eb = (const unsigned char*)s_cf + (py * RS + px) * 8;
-                const unsigned char* gb = (const unsigned char*)s_gk + (py * RS + px) * 8;
-                double r0 = 0.0, r1 = 0.0;
-                unsigned best = 0;
-                const unsigned kb = 1023u - 2u * (unsigned)l;
-                auto block = [&](int i, bool first) {
-                    const ushort2 o = s_off[l * NE + i];
-                    const double ca = *(const double*)(eb + o.x);
-                    const double cc = *(const double*)(eb + o.y);
-                    const unsigned az = *(const unsigned*)(gb + o.x), cz = *(const unsigned*)(gb + o.y);
-                    if (first) { r0 = ca; r1 = cc; } else { r0 += ca; r1 += cc; }
-                    const unsigned ka = az + (kb - 8u * i), kc = cz + (kb - 8u * i - 1u);
-                    best = ka > best ? ka : best;
-                    best = kc > best ? kc : best;
-                };
-                // the four lanes' accumulator pairs combined in NumPy's tree order
-                auto leaf_sum = [&]() {
-                    double t = r0 + r1;
-                    t = t + dpp_f64<DPP_QUAD_XOR1>(t);
-                    return t + dpp_f64<DPP_QUAD_XOR2>(t);
-                };
-#pragma unroll 5
-                for (int i = 0; i < NA; ++i) block(i, i == 0);
-                double t = leaf_sum();
-                constexpr int EL = PT * PT - 1;   // the one tail element: PT*PT = 1 (mod 8)
-                const double tl_ = *(const double*)(eb + ((PT - 1) * RS + (PT - 1)) * 8);
-                const unsigned tlz = *(const unsigned*)(gb + ((PT - 1) * RS + (PT - 1)) * 8);
-                if constexpr (NA < NE) {
-                    // second half of the split: its own leaf, then its tail, then the halves are added
-#pragma unroll 5
-                    for (int i = NA; i < NE; ++i) block(i, i == NA);
-                    double t2 = leaf_sum();
-                    t2 += tl_;
-                    t = t + t2;
-                } else {
-                    t += tl_;
-                }
-                unsigned ob = (unsigned)dpp_i32<DPP_QUAD_XOR1>((int)best);
-                best = ob > best ? ob : best;
-                ob = (unsigned)dpp_i32<DPP_QUAD_XOR2>((int)best);
-                best = ob > best ? ob : best;
-                const unsigned kt = tlz + (1023u - (unsigned)EL);
-                best = kt > best ? kt : best;
-                const int be = 1023 - (int)(best & 1023u);
-                const int brow = be / (PT > 0 ? PT : 1), bcol = be - brow * PT;
-                const int bpk = (int)((const uint2*)gb)[brow * RS + bcol].y;
-                ev = finish_front_pixel(t / (double)p.psq, nb, F, bpk);
-            } else {
-                ev = eval_front_pixel<(PT > 0 ? (PT * PT > 128 ? 1 : 0) : 3)>(p, vgrad, vconf, fy, fx, F, nb, l);
-            }
-            if (l == 0) {
-                const int pos = fy * W + fx;
-                cnxt[pos] = ev.cnew;
-                if (fresh) dterm[pos] = ev.data;
-                if (better_prio(ev.prio, pos, bestP, bestI)) { bestP = ev.prio; bestI = pos; }
-            }
-        }
+        prio_eval_tile<PT>(p, s_cf, s_gk, s_list, s_mask, s_off, RS, ty0, tx0, n, fresh, dterm, cnxt, grp, l,
+                           bestP, bestI);
         if (ti == bx) STAMP_MID(7);
         __syncthreads();   // the staging buffers are reused by the next tile
     }
@@ -1052,6 +1073,8 @@ __global__ __launch_bounds__(256) void k_select(Params p) {
     const int live = st->live;
     const unsigned n = (unsigned)p.pgrid;   // one slot per wave of the priority stage
     const int cur = st->cur;
+    const int st_iter = st->iter, st_remaining = st->remaining, st_tlsel = st->tlsel;
+    const unsigned st_tcount = st->tcount;
     if (!live) {
         if (tid == 0) d->live = 0;
         return;
@@ -1137,8 +1160,8 @@ __global__ __launch_bounds__(256) void k_select(Params p) {
         }
         s_k[e] = (uint8_t)k;
         s_t[0][e] = (int8_t)t0; s_t[1][e] = (int8_t)t1; s_t[2][e] = (int8_t)t2;
+        d->kflat[e] = (uint8_t)k;   // also tells the update which pixels of the patch it fills
         if (!mfma_path) {   // flat templates: read by the unspecialised search only
-            d->kflat[e] = (uint8_t)k;
             d->tflat[0][e] = (int8_t)t0; d->tflat[1][e] = (int8_t)t1; d->tflat[2][e] = (int8_t)t2;
         }
     }
@@ -1213,6 +1236,10 @@ __global__ __launch_bounds__(256) void k_select(Params p) {
         d->cnew = cnew_t;
         d->ty = (double)(r0 + r1) / 2.0;
         d->tx = (double)(c0 + c1) / 2.0;
+        d->nfill = ph * pw - s_nk;
+        d->cur = cur; d->iter = st_iter; d->remaining = st_remaining;
+        d->tlsel = st_tlsel; d->tcount = st_tcount;
+        d->t_select = (long long)wall_clock64();
         st->pcount = 0;
         st->scount = 0;
         st->bound = 0x7fffffff;
@@ -1928,6 +1955,8 @@ void k_search_pipe(Params p) {
         for (int k = 0; k < NSPEC; ++k) spec[k] = pl_[imin(tid + 256 * k, p.pgrid - 1)];
         const int live = st->live;
         const int cur = st->cur;
+        const int st_iter = st->iter, st_remaining = st->remaining, st_tlsel = st->tlsel;
+        const unsigned st_tcount = st->tcount;
         Desc* dw = p.desc + b;   // the first block of the image writes what k_update reads
         if (!live) {
             if (sub_ == 0 && tid == 0) dw->live = 0;
@@ -1969,6 +1998,8 @@ void k_search_pipe(Params p) {
             dw->ncy = sel.ncy; dw->ncx = sel.ncx;
             dw->ty = sel.ty; dw->tx = sel.tx;
             dw->cnew = p.conf[((size_t)b * 2 + (cur ^ 1)) * ((size_t)H * W) + pos];
+            dw->cur = cur; dw->iter = st_iter; dw->remaining = st_remaining;
+            dw->tlsel = st_tlsel; dw->tcount = st_tcount;
         }
     }
     const int ncy = SELECT ? sel.ncy : d->ncy, ncx = SELECT ? sel.ncx : d->ncx;
@@ -2093,6 +2124,7 @@ void k_search_pipe(Params p) {
                 }
                 s_sk[tid] = (uint8_t)k;
                 s_st[0][tid] = (int8_t)t0; s_st[1][tid] = (int8_t)t1; s_st[2][tid] = (int8_t)t2;
+                if (sub_ == 0) (p.desc + b)->kflat[tid] = (uint8_t)k;   // tells the update which pixels it fills
             }
             soff_l = wave_fold_i32<false>(soff_l);
             nk_l = wave_fold_i32<false>(nk_l);
@@ -2108,6 +2140,10 @@ void k_search_pipe(Params p) {
         publish_barrier<63>();                 // LDS only: the tile loads stay in flight
         soff = s_red[0] + 24576 * s_red[1];
         chmask = s_red[3] & (CHROMA ? 7 : 1);
+        if (sub_ == 0 && tid == 0) {
+            (p.desc + b)->nfill = sel.ph * sel.pw - s_red[1];
+            (p.desc + b)->t_select = (long long)wall_clock64();
+        }
         if (tid < NZ) {
             const int row = tid % (2 * NS), type = tid / (2 * NS);
             unsigned long long lo = 0, hi = 0;
@@ -2482,6 +2518,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PM <= 9 ? 8
     ImgState* st = p.st + b;
     const Desc* __restrict__ d = p.desc + b;
     const int tid = threadIdx.x;
+    const long long t_entry = tid == 0 ? (long long)wall_clock64() : 0;   // the search ended about here
     const int H = p.H, W = p.W, P = p.P;
     const size_t HW = (size_t)H * W;
     constexpr int MR = 3 * PM - 2 + 2;  // mask region edge: patch grown by max(P-1, 2) per side
@@ -2520,6 +2557,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PM <= 9 ? 8
     const int cur = st->cur;
     const int remaining0 = st->remaining, iter0 = st->iter;
     const unsigned tcount0 = st->tcount;
+    const int tlsel = st->tlsel;
     const int ncx = d->ncx;
     // entries to reduce: the exchange slots of a split search, else the slots of the search blocks
     // inside the candidate grid
@@ -2795,7 +2833,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PM <= 9 ? 8
         const int delta = s_td[tid];
         if (delta != 0 && tty0 + ti < p.tny && ttx0 + tj < p.tnx) {
             int* tf = p.tfront + (size_t)b * p.tnx * p.tny;
-            int* tl = p.tlist + (size_t)b * p.tcap;
+            int* tl = p.tlist + ((size_t)b * 2 + tlsel) * p.tcap;
             const int tile = (tty0 + ti) * p.tnx + ttx0 + tj;
             const int now = tf_old + delta;
             __hip_atomic_store(&tf[tile], now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2858,7 +2896,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PM <= 9 ? 8
         const int lane = tid & 63, wv = tid >> 6;
         const int nt = p.tnx * p.tny;
         int* tf = p.tfront + (size_t)b * nt;
-        int* tl = p.tlist + (size_t)b * p.tcap;
+        int* tl = p.tlist + ((size_t)b * 2 + tlsel) * p.tcap;
         unsigned base = 0;
         for (int t0 = 0; t0 < nt; t0 += 256) {
             const int t = t0 + tid;
@@ -2890,6 +2928,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PM <= 9 ? 8
             rec.tr = d->tr; rec.tc = d->tc; rec.sy = sy; rec.sx = sx;
             rec.cost = src_cost; rec.remaining = rem;
             p.trace[(size_t)b * p.trace_cap + it] = rec;
+            if (p.stime) p.stime[(size_t)b * p.trace_cap + it] = (float)(t_entry - d->t_select) * 0.01f;
         }
         st->remaining = rem;
         st->iter = it + 1;
@@ -2900,3 +2939,5 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PM <= 9 ? 8
     }
     STAMP(23);
 }
+
+#include "crim_step.h"

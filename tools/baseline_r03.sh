@@ -17,3 +17,9 @@ done
 D=/tmp/k_ds.$$
 timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 $R/tools/dataset_run.py 2>&1 | grep "lock-step" || exit 1
 python3 $R/tools/kstats.py $D/*/*kernel_stats.csv | tee $O/kstats_dataset.txt
+# the same runs without the profiler: the time per iteration as the host sees it
+for CASE in "2048 9" "2048 15" "4096 9"; do
+  set -- $CASE
+  timeout -k 10 120 python3 $R/tools/solo_profile.py 1 20000 $1 $2 | tee -a $O/unprofiled.txt || exit 1
+done
+timeout -k 10 120 python3 $R/tools/dataset_run.py 5 | tee -a $O/unprofiled.txt
