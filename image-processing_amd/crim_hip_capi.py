@@ -92,6 +92,18 @@ def load_library():
     lib.crim_trace.argtypes = [vp, ci, vp, cl, ctypes.POINTER(cl)]
     lib.crim_iterations.restype = ci
     lib.crim_iterations.argtypes = [vp, ci, ctypes.POINTER(cl)]
+    lib.crim_search_times.restype = ci
+    lib.crim_search_times.argtypes = [vp, ci, vp, cl, ctypes.POINTER(cl)]
+    lib.crim_noalloc_bytes_needed.restype = ctypes.c_size_t
+    lib.crim_noalloc_bytes_needed.argtypes = [ci, ci, ci]
+    lib.crim_debug_state.restype = ci
+    lib.crim_debug_state.argtypes = [vp, ci, vp]
+    lib.crim_debug_fill_tile_list.restype = ci
+    lib.crim_debug_fill_tile_list.argtypes = [vp, ci]
+    lib.crim_debug_dterm.restype = ci
+    lib.crim_debug_dterm.argtypes = [vp, ci, vp]
+    lib.crim_debug_stamps.restype = ci
+    lib.crim_debug_stamps.argtypes = [vp, vp]
     lib.crim_lab_tables.restype = ci
     lib.crim_lab_tables.argtypes = [vp, vp, vp]
     lib.crim_profile.restype = ci
@@ -177,6 +189,12 @@ def filter_noise(images, median_ksize=3, nlm_h=7, apply_sharpening=True, device=
 
 
 NOALLOC_MAX_PIXELS = 512 * 512
+NOALLOC_BYTES = 52 * NOALLOC_MAX_PIXELS + (1 << 18)
+
+
+def noalloc_bytes_needed(height, width, patch_size):
+    """Bytes of the static device array a crim_inpaint_noalloc call for this shape uses (no GPU needed)."""
+    return int(load_library().crim_noalloc_bytes_needed(int(height), int(width), int(patch_size)))
 
 
 def inpaint_noalloc(height, width, patch_size, d_bgr_ptr, d_mask_ptr, d_out_ptr, device=0):
@@ -319,6 +337,15 @@ class Engine:
         _check(load_library().crim_trace(self._h, int(index), None, 0, ctypes.byref(n)))
         buf = np.zeros(max(n.value, 1), ITER_REC_DTYPE)
         _check(load_library().crim_trace(self._h, int(index), buf.ctypes.data, n.value, ctypes.byref(n)))
+        return buf[:n.value]
+
+    def search_times(self, index=0):
+        """Microseconds each executed iteration spent between the end of its target selection and the start
+        of its update (the search launch), as float32; empty under FLAG_NO_TRACE."""
+        n = ctypes.c_long()
+        _check(load_library().crim_search_times(self._h, int(index), None, 0, ctypes.byref(n)))
+        buf = np.zeros(max(n.value, 1), np.float32)
+        _check(load_library().crim_search_times(self._h, int(index), buf.ctypes.data, n.value, ctypes.byref(n)))
         return buf[:n.value]
 
     def profile(self):

@@ -97,11 +97,15 @@ class Criminisi_Inpainter():
         self._engine = None
         self._fields_stale = False
         self.iterations = 0
+        self.search_seconds = None   # verbose runs: per-iteration 'Time to find best', in seconds
 
     # front / data / priority (criminisi_inpainter.py:31,37,38) are materialised on demand: the
     # fill loop never needs them as full frames.  After inpaint() the reference holds the frames its
     # LAST iteration computed before its update (:53-59); they are reproduced, when first read, by
     # filling the same input once more up to the last iteration and evaluating the fields there.
+    # Cost: the first read of any of the three after inpaint() runs the whole fill a second time on an
+    # engine of its own (as long as inpaint() itself took); later reads are free.  Callers that never
+    # read them -- the reference's own pipeline does not -- pay nothing.
     def _refresh_fields(self):
         if self._fields_stale and self._engine is not None:
             img = np.ascontiguousarray(self.image, dtype=np.uint8)
@@ -150,7 +154,9 @@ class Criminisi_Inpainter():
             # Neither side effect puts the host into the loop: the fill keeps replaying graphs, a
             # chunk of iterations per call, and both are produced behind it from the device's
             # per-iteration records.  verbose (:67-69, :76-77): the lines of a chunk are printed
-            # together; 'Time to find best' is the chunk's wall time divided by its iterations.
+            # together; 'Time to find best' is that iteration's own search time, measured on the
+            # device (end of the target selection to the start of the update; the reference brackets
+            # _find_source_patch with time.time(), :64-69).
             # show_progress (:55-57): frame c is the working image before iteration c's update, i.e.
             # the input with the first c patch copies of the trace applied -- rebuilt on the host
             # and encoded by worker threads while the GPU runs the next chunk.
@@ -158,15 +164,16 @@ class Criminisi_Inpainter():
             shown = 0
             try:
                 while True:
-                    chunk_start = time.time()
                     _, remaining = eng.run(max_iters=self.VERBOSE_CHUNK)
                     recs = eng.trace(0)
-                    per_iter = (time.time() - chunk_start) / max(len(recs) - shown, 1)
-                    for r in recs[shown:]:
+                    found_us = eng.search_times(0) if self.verbose else None
+                    self.search_seconds = None if found_us is None else found_us.astype(np.float64) * 1e-6
+                    for k in range(shown, len(recs)):
+                        r = recs[k]
                         if frames is not None:
                             frames.emit_then_apply(r)
                         if self.verbose:
-                            print('Time to find best: %.2f seconds' % per_iter)
+                            print('Time to find best: %.2f seconds' % (1e-6 * float(found_us[k])))
                             print('%d of %d completed' % (total - int(r['remaining']), total))
                     shown = len(recs)
                     if remaining == 0:

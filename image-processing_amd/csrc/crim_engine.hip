@@ -228,6 +228,33 @@ static bool search_selects(const Params& p) {
     return p.selsearch && !p.generic && !p.dot4 && p.pipe_t > 0 && p.P >= 3 && p.P <= 15 && (p.P & 1);
 }
 
+// Every instance of the matrix-core search kernels, looked up by (patch edge, colour planes, selects):
+// one table per patch edge, so that a launch site cannot name a wrong <P, CHROMA, SELECT> triple.
+typedef void (*SearchKernel)(Params);
+template <int P>
+struct SearchInstances {
+    static constexpr SearchKernel pipe[2][2] = {{k_search_pipe<P, false, false>, k_search_pipe<P, false, true>},
+                                               {k_search_pipe<P, true, false>, k_search_pipe<P, true, true>}};
+    static constexpr SearchKernel mfma[2] = {k_search_mfma<P, false>, k_search_mfma<P, true>};
+};
+template <template <int> class F, typename R, typename... A>
+static R by_patch_edge(int P, R none, A... a) {
+    switch (P) {
+        case 3: return F<3>::get(a...);
+        case 5: return F<5>::get(a...);
+        case 7: return F<7>::get(a...);
+        case 9: return F<9>::get(a...);
+        case 11: return F<11>::get(a...);
+        case 13: return F<13>::get(a...);
+        case 15: return F<15>::get(a...);
+        default: return none;
+    }
+}
+template <int P> struct PipeGet { static SearchKernel get(bool chroma, bool sel) { return SearchInstances<P>::pipe[chroma][sel]; } };
+template <int P> struct MfmaGet { static SearchKernel get(bool chroma) { return SearchInstances<P>::mfma[chroma]; } };
+static SearchKernel pipe_kernel(int P, bool chroma, bool sel) { return by_patch_edge<PipeGet, SearchKernel>(P, nullptr, chroma, sel); }
+static SearchKernel mfma_kernel(int P, bool chroma) { return by_patch_edge<MfmaGet, SearchKernel>(P, nullptr, chroma); }
+
 static void launch_search(const Params& pin, hipStream_t s, int sy0 = 0, int rows = -1, bool sel = false) {
     Params p = pin;
     p.sy0 = sy0;
@@ -249,30 +276,19 @@ static void launch_search(const Params& pin, hipStream_t s, int sy0 = 0, int row
             int T = std::min(pipe_t, rows);
             const long min_blocks = p.pipe_min_blocks;
             while (T > 1 && (long)p.mgx * ((rows + T - 1) / T) * p.B < min_blocks) T = (T + 1) / 2;
+            if (p.pipe_force > 0) T = std::min(p.pipe_force, rows);
             p.mtiles = T;
             p.mchunks = (rows + T - 1) / T;
             dim3 pgrid((unsigned)p.mgx * p.mchunks * p.B);
-            switch (p.P) {
-                case 3: if (p.chroma) { if (sel) hipLaunchKernelGGL((k_search_pipe<3, true, true>), pgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_pipe<3, true, false>), pgrid, block, 0, s, p); } else { if (sel) hipLaunchKernelGGL((k_search_pipe<3, false, true>), pgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_pipe<3, false, false>), pgrid, block, 0, s, p); } return;
-                case 5: if (p.chroma) { if (sel) hipLaunchKernelGGL((k_search_pipe<5, true, true>), pgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_pipe<5, true, false>), pgrid, block, 0, s, p); } else { if (sel) hipLaunchKernelGGL((k_search_pipe<5, false, true>), pgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_pipe<5, false, false>), pgrid, block, 0, s, p); } return;
-                case 7: if (p.chroma) { if (sel) hipLaunchKernelGGL((k_search_pipe<7, true, true>), pgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_pipe<7, true, false>), pgrid, block, 0, s, p); } else { if (sel) hipLaunchKernelGGL((k_search_pipe<7, false, true>), pgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_pipe<7, false, false>), pgrid, block, 0, s, p); } return;
-                case 9: if (p.chroma) { if (sel) hipLaunchKernelGGL((k_search_pipe<9, true, true>), pgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_pipe<9, true, false>), pgrid, block, 0, s, p); } else { if (sel) hipLaunchKernelGGL((k_search_pipe<9, false, true>), pgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_pipe<9, false, false>), pgrid, block, 0, s, p); } return;
-                case 11: if (p.chroma) { if (sel) hipLaunchKernelGGL((k_search_pipe<11, true, true>), pgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_pipe<11, true, false>), pgrid, block, 0, s, p); } else { if (sel) hipLaunchKernelGGL((k_search_pipe<11, false, true>), pgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_pipe<11, false, false>), pgrid, block, 0, s, p); } return;
-                case 13: if (p.chroma) { if (sel) hipLaunchKernelGGL((k_search_pipe<13, true, true>), pgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_pipe<13, true, false>), pgrid, block, 0, s, p); } else { if (sel) hipLaunchKernelGGL((k_search_pipe<13, false, true>), pgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_pipe<13, false, false>), pgrid, block, 0, s, p); } return;
-                case 15: if (p.chroma) { if (sel) hipLaunchKernelGGL((k_search_pipe<15, true, true>), pgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_pipe<15, true, false>), pgrid, block, 0, s, p); } else { if (sel) hipLaunchKernelGGL((k_search_pipe<15, false, true>), pgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_pipe<15, false, false>), pgrid, block, 0, s, p); } return;
-                default: break;
+            if (const SearchKernel k = pipe_kernel(p.P, p.chroma != 0, sel)) {
+                hipLaunchKernelGGL(k, pgrid, block, 0, s, p);
+                return;
             }
         }
         dim3 mgrid((unsigned)p.mgx * rows * p.B);
-        switch (p.P) {
-            case 3: if (p.chroma) hipLaunchKernelGGL((k_search_mfma<3, true>), mgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_mfma<3, false>), mgrid, block, 0, s, p); return;
-            case 5: if (p.chroma) hipLaunchKernelGGL((k_search_mfma<5, true>), mgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_mfma<5, false>), mgrid, block, 0, s, p); return;
-            case 7: if (p.chroma) hipLaunchKernelGGL((k_search_mfma<7, true>), mgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_mfma<7, false>), mgrid, block, 0, s, p); return;
-            case 9: if (p.chroma) hipLaunchKernelGGL((k_search_mfma<9, true>), mgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_mfma<9, false>), mgrid, block, 0, s, p); return;
-            case 11: if (p.chroma) hipLaunchKernelGGL((k_search_mfma<11, true>), mgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_mfma<11, false>), mgrid, block, 0, s, p); return;
-            case 13: if (p.chroma) hipLaunchKernelGGL((k_search_mfma<13, true>), mgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_mfma<13, false>), mgrid, block, 0, s, p); return;
-            case 15: if (p.chroma) hipLaunchKernelGGL((k_search_mfma<15, true>), mgrid, block, 0, s, p); else hipLaunchKernelGGL((k_search_mfma<15, false>), mgrid, block, 0, s, p); return;
-            default: break;
+        if (const SearchKernel k = mfma_kernel(p.P, p.chroma != 0)) {
+            hipLaunchKernelGGL(k, mgrid, block, 0, s, p);
+            return;
         }
     }
     switch (p.P) {
@@ -412,6 +428,8 @@ static void init_geometry(Params& p, int batch, int H, int W, int patch_size, un
         p.pipe_t = e ? atoi(e) : 8;
         e = getenv("CRIM_PIPE_MIN_BLOCKS");
         p.pipe_min_blocks = e ? atoi(e) : 512;
+        e = getenv("CRIM_PIPE_TILES");      // experiments: exactly this many rows of tiles per block
+        p.pipe_force = e ? atoi(e) : 0;
     }
     // priority waves per image: a wave's fixed cost (state, set-up: about 3 us) is shared by the tiles it
     // walks, so large batches, which fill the GPU anyway, get few waves per image
@@ -435,9 +453,24 @@ static void init_geometry(Params& p, int batch, int H, int W, int patch_size, un
     // far wave (a multiple of 4: four waves per block), at most 1024 in all (what a search block reads
     // in one batch of loads).
     p.fused = (search_selects(p) && !(flags & (CRIM_FLAG_EAGER | CRIM_FLAG_PROFILE | CRIM_FLAG_PROFILE_SOLO))) ? 1 : 0;
-    if (const char* e = getenv("CRIM_FUSED")) p.fused = (p.fused && atoi(e)) ? 1 : 0;
+    // images a launch covers: a batch of 32 or more advances as two lanes (crim_create_batch)
+    const int lane_batch = (batch >= 32 && !(flags & CRIM_FLAG_ONE_LANE)) ? (batch + 1) / 2 : batch;
+    // It pays where iterations wait for launches and round trips, not where the launches fill the GPU many
+    // times over (measured: 100 x 256^2 -20 % per iteration, 800 x 512^2 +5 %): up to 4096 search tiles per launch.
+    const long search_tiles = (long)lane_batch * ((std::max(W - p.half, 1) + MS_W - 1) / MS_W) * p.sny;
+    if (search_tiles > 4096) p.fused = 0;
+    if (const char* e = getenv("CRIM_FUSED")) p.fused = (search_selects(p) && atoi(e)) ? 1 : 0;
     if (p.fused) {
-        p.nfar = std::max(4, std::min(p.pgrid, 1024 - CRIM_NEAR_TILES - 3) / 4 * 4);
+        // far waves per image: as many as the tile list may need, but the launch should be resident at
+        // once (k_step runs three blocks of four waves per CU; 3 blocks of an image are its near tiles,
+        // one its bookkeeping): measured on 50 images per launch, 14-15 blocks per image 39 us per
+        // iteration, 16 blocks 43.5 us
+        const int resident_blocks = 3 * 256;
+        int far_blocks = resident_blocks / lane_batch - 1 - (CRIM_NEAR_TILES + 3) / 4;
+        far_blocks = std::max(2, std::min(far_blocks, (1024 - CRIM_NEAR_TILES - 3) / 4));
+        far_blocks = std::min(far_blocks, (p.tnx * p.tny + 3) / 4);
+        p.nfar = 4 * far_blocks;
+        if (getenv("CRIM_PGRID")) p.nfar = std::max(4, std::min(p.pgrid, 1024 - CRIM_NEAR_TILES - 3) / 4 * 4);
         p.pgrid = CRIM_NEAR_TILES + p.nfar;
         p.kblocks = 1 + (CRIM_NEAR_TILES + 3) / 4 + p.nfar / 4;
     }
@@ -1205,7 +1238,6 @@ extern "C" int crim_peek_fields(crim_t* h, int index, uint8_t* front_out, double
 // array (at its own address) until the process ends.  The array keeps the last call's contents:
 // whatever must start from a known value is cleared or rewritten at the top of each call.
 
-#define CRIM_NOALLOC_BYTES ((size_t)52 * CRIM_NOALLOC_MAX_PIXELS + ((size_t)1 << 18))
 static __device__ __align__(256) unsigned char scratch[CRIM_NOALLOC_BYTES];
 
 namespace {
@@ -1241,6 +1273,52 @@ struct Carver {
 };
 }  // namespace
 
+// Lays the engine state of one H x W image out in the array at `base` (null: sizes only); returns the
+// bytes used.
+struct NoallocLayout {
+    Params p;
+    uint16_t *d_gamma = nullptr, *d_cbrt = nullptr;
+    size_t planes_bytes = 0, invalid_bytes = 0, invbits_bytes = 0, used = 0;
+};
+static void noalloc_layout(NoallocLayout& L, int H, int W, int patch_size, unsigned char* base) {
+    Params& p = L.p;
+    init_geometry(p, 1, H, W, patch_size, 0);
+    const size_t HW = (size_t)H * W;
+    const LabTables& t = lab_tables();
+    memcpy(p.coef, t.coef, sizeof(p.coef));
+    L.planes_bytes = (size_t)CRIM_NPL * H * p.Wp + (size_t)64 * p.Wp;
+    L.invalid_bytes = (size_t)H * p.Wi;
+    L.invbits_bytes = (size_t)H * p.Wb * sizeof(unsigned long long);
+    Carver c{base};
+    c.take(&p.bgr, HW * 3);
+    c.take(&p.planes, L.planes_bytes);
+    c.take(&p.mask, HW);
+    c.take(&p.grey, HW);
+    c.take(&p.grad, HW * sizeof(int));
+    c.take(&p.conf, 2 * HW * sizeof(double));
+    c.take(&p.dterm, HW * sizeof(double));
+    c.take(&p.invalid, L.invalid_bytes);
+    c.take(&p.invbits, L.invbits_bytes);
+    c.take(&p.tfront, (size_t)p.tnx * p.tny * sizeof(int));
+    c.take(&p.tlist, (size_t)2 * p.tcap * sizeof(int));
+    c.take(&p.st, sizeof(ImgState));
+    c.take(&p.desc, sizeof(Desc));
+    c.take(&p.plist, (size_t)p.pgrid * sizeof(PEntry));
+    c.take(&p.slist, (size_t)p.snx * p.sny * sizeof(SEntry));
+    c.take(&p.dbg, kDbgSlots * sizeof(long long));
+    c.take(&p.xchg, 64 * sizeof(SEntry));
+    c.take(&L.d_gamma, sizeof(t.gamma));
+    c.take(&L.d_cbrt, sizeof(t.cbrt_));
+    L.used = c.used;
+}
+
+extern "C" size_t crim_noalloc_bytes_needed(int H, int W, int patch_size) {
+    if (H < 1 || W < 1 || patch_size < 1 || patch_size > CRIM_MAX_PATCH) return 0;
+    NoallocLayout L;
+    noalloc_layout(L, H, W, patch_size, nullptr);
+    return L.used;
+}
+
 extern "C" int crim_inpaint_noalloc(int H, int W, int patch_size, int device, const void* d_bgr,
                                     const void* d_mask, void* d_bgr_out, long* iters_done) {
     if (!d_bgr || !d_mask || !d_bgr_out) return fail(CRIM_ERR_ARG, "crim_inpaint_noalloc: null argument");
@@ -1261,35 +1339,14 @@ extern "C" int crim_inpaint_noalloc(int H, int W, int patch_size, int device, co
         const int rc = scratch_base(device, &base);
         if (rc) return rc;
     }
-    Params p;
-    init_geometry(p, 1, H, W, patch_size, 0);
+    NoallocLayout lay;
+    noalloc_layout(lay, H, W, patch_size, base);
+    Params& p = lay.p;
     const size_t HW = (size_t)H * W;
     const LabTables& t = lab_tables();
-    memcpy(p.coef, t.coef, sizeof(p.coef));
-    const size_t planes_bytes = (size_t)CRIM_NPL * H * p.Wp + (size_t)64 * p.Wp;
-    const size_t invalid_bytes = (size_t)H * p.Wi;
-    const size_t invbits_bytes = (size_t)H * p.Wb * sizeof(unsigned long long);
-    uint16_t *d_gamma = nullptr, *d_cbrt = nullptr;
-    Carver c{base};
-    c.take(&p.bgr, HW * 3);
-    c.take(&p.planes, planes_bytes);
-    c.take(&p.mask, HW);
-    c.take(&p.grey, HW);
-    c.take(&p.grad, HW * sizeof(int));
-    c.take(&p.conf, 2 * HW * sizeof(double));
-    c.take(&p.dterm, HW * sizeof(double));
-    c.take(&p.invalid, invalid_bytes);
-    c.take(&p.invbits, invbits_bytes);
-    c.take(&p.tfront, (size_t)p.tnx * p.tny * sizeof(int));
-    c.take(&p.tlist, (size_t)2 * p.tcap * sizeof(int));
-    c.take(&p.st, sizeof(ImgState));
-    c.take(&p.desc, sizeof(Desc));
-    c.take(&p.plist, (size_t)p.pgrid * sizeof(PEntry));
-    c.take(&p.slist, (size_t)p.snx * p.sny * sizeof(SEntry));
-    c.take(&p.dbg, kDbgSlots * sizeof(long long));
-    c.take(&p.xchg, 64 * sizeof(SEntry));
-    c.take(&d_gamma, sizeof(t.gamma));
-    c.take(&d_cbrt, sizeof(t.cbrt_));
+    const size_t planes_bytes = lay.planes_bytes, invalid_bytes = lay.invalid_bytes, invbits_bytes = lay.invbits_bytes;
+    uint16_t *d_gamma = lay.d_gamma, *d_cbrt = lay.d_cbrt;
+    struct { size_t used; } c{lay.used};
     if (c.used > CRIM_NOALLOC_BYTES)
         return fail(CRIM_ERR_ARG, "crim_inpaint_noalloc: a %d x %d image needs %zu bytes of state, the static "
                     "buffer holds %zu (rows narrower than 32 pixels are padded heavily; use crim_create / crim_run)",

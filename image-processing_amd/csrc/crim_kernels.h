@@ -32,7 +32,13 @@
         /* the shader clock beside the wall clock for one block: their ratio is the clock rate under load */ \
         if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2 + 5) p.dbg[56 + (which)] = clock64(); \
     } while (0)
+// the same for thread 0 of the block with linear id `blk`
+#define STAMP_AT(blk, slot)                                                                 \
+    do {                                                                                    \
+        if (threadIdx.x == 0 && blockIdx.x == (blk)) p.dbg[slot] = wall_clock64();          \
+    } while (0)
 #else
+#define STAMP_AT(blk, slot) do {} while (0)
 #define STAMP(slot) do {} while (0)
 #define STAMP_MID(slot) do {} while (0)
 #define STAMP_BLOCK(which) do {} while (0)
@@ -1940,6 +1946,7 @@ void k_search_pipe(Params p) {
     __shared__ int s_red[7];   // soff, nk, rowmask, chmask; SELECT: ph, pw of the target patch (read by the rare clipped path)
     // target geometry worked out by this block (SELECT only)
     struct { int ncy, ncx, clipped, r0, c0, ph, pw; double ty, tx; } sel = {};
+    int sel_bound = 0x7fffffff;   // SELECT: the image's pruning bound as it stood when the block started
     if constexpr (!SELECT) {
         if (!d->live) return;
     } else {
@@ -1957,6 +1964,9 @@ void k_search_pipe(Params p) {
         const int cur = st->cur;
         const int st_iter = st->iter, st_remaining = st->remaining, st_tlsel = st->tlsel;
         const unsigned st_tcount = st->tcount;
+        // (read with the rest of the loop state: a load of its own further down would hold the wave that
+        // issues it for a round trip; a stale bound only prunes less)
+        sel_bound = st->bound;
         Desc* dw = p.desc + b;   // the first block of the image writes what k_update reads
         if (!live) {
             if (sub_ == 0 && tid == 0) dw->live = 0;
@@ -2021,7 +2031,8 @@ void k_search_pipe(Params p) {
     const double ty = SELECT ? sel.ty : d->ty, tx = SELECT ? sel.tx : d->tx;
     int bound0 = 0;
     if (tid == 0) {
-        bound0 = __hip_atomic_load(&p.st[b].bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (SELECT) bound0 = sel_bound;
+        else bound0 = __hip_atomic_load(&p.st[b].bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_bound = bound0;
     }
     const uint8_t* inv = p.invalid + (size_t)b * H * p.Wi;

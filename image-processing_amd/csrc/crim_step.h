@@ -17,7 +17,7 @@
 //
 // Block kinds of image b (p.kblocks blocks per image):
 //   0          bookkeeping: mask, confidence buffers, validity maps, tile counts and list, loop state
-//   1 .. 3     near tiles 4 (k - 1) .. 4 (k - 1) + 3, one per wave; block 1 also copies the pixels,
+//   1 .. 3     near tiles 4 (k - 1) .. 4 (k - 1) + 3, one per wave; block 3 also copies the pixels,
 //              rewrites the gradient around the patch and records the iteration
 //   4 ..       far tiles: wave w of these blocks walks entries w, w + p.nfar, ... of the tile list
 // Every wave of kinds 1.. owns one slot of the image's priority list, as the waves of k_priority do.
@@ -139,6 +139,19 @@ __device__ __forceinline__ void tile_commit(const Params& p, const TileStage<PT>
     }
     const int scol = lane & 31;
     const int xx = imin(imax(st.tx0 - half + scol, 0), W - 1);
+    // the override tables are read for every row first (from clamped positions, all reads in flight
+    // together), and applied afterwards
+    uint8_t okf[OVR ? L::NRB : 1];
+    if (OVR) {
+        const int j = xx - ov.c0;
+        const int jk = imin(imax(j, 0), ov.pw - 1);
+#pragma unroll
+        for (int k = 0; k < L::NRB; ++k) {
+            const int yy = imin(imax(st.ty0 - half + (lane >> 5) + 2 * k, 0), H - 1);
+            const int i = yy - ov.r0;
+            okf[k] = ov.kflat[imin(imax(i, 0), ov.ph - 1) * PT + jk];
+        }
+    }
 #pragma unroll
     for (int k = 0; k < L::NRB; ++k) {
         const int row = (lane >> 5) + 2 * k;
@@ -148,8 +161,7 @@ __device__ __forceinline__ void tile_commit(const Params& p, const TileStage<PT>
             if (OVR) {
                 const int yy = imin(imax(st.ty0 - half + row, 0), H - 1);
                 const int i = yy - ov.r0, j = xx - ov.c0;
-                if (i >= 0 && i < ov.ph && j >= 0 && j < ov.pw && ov.kflat[i * PT + j] == 0) c = ov.cnew;
-                if (i >= -1 && i <= ov.ph && j >= -1 && j <= ov.pw) g = ov.ngrad[(i + 1) * (PT + 2) + (j + 1)];
+                if (i >= 0 && i < ov.ph && j >= 0 && j < ov.pw && okf[k] == 0) c = ov.cnew;
             }
             w.s_cf[row * L::RS + scol] = c;
             if (GRAD) {
@@ -157,6 +169,28 @@ __device__ __forceinline__ void tile_commit(const Params& p, const TileStage<PT>
                 w.s_gk[row * L::RS + scol] = make_uint2((uint32_t)(gy2 * gy2 + gx2 * gx2) << 10, (uint32_t)g);
             }
         }
+    }
+}
+
+// The staged gradient records of the pixels within one pixel of the patch, rewritten from the gradient
+// after the fill (ov.ngrad), once that is known: tile_commit<.., true, true> stages the tile from memory
+// with the mask and confidence overrides alone, so that it can run before the source window is known.
+template <int PT>
+__device__ __forceinline__ void tile_patch_gradient(const Params& p, int ty0, int tx0, const PrioLds<PT>& w,
+                                                    const PatchOverride& ov, int lane) {
+    using L = PrioLds<PT>;
+    const int H = p.H, W = p.W, half = p.half;
+    const int bh = ov.ph + 2, bw = ov.pw + 2;
+    // Staged record (row, col) holds the pixel at the CLAMPED position (ty0 - half + row, tx0 - half + col);
+    // records beyond the image are never read, so only in-image pixels are visited.
+    for (int e = lane; e < bh * bw; e += 64) {
+        const int i = e / bw, j = e - i * bw;
+        const int yy = ov.r0 - 1 + i, xx = ov.c0 - 1 + j;
+        const int row = yy - (ty0 - half), col = xx - (tx0 - half);
+        if (yy < 0 || yy >= H || xx < 0 || xx >= W || row < 0 || row >= L::RS || col < 0 || col >= L::RS) continue;
+        const int g = ov.ngrad[i * (PT + 2) + j];
+        const int gy2 = (int)(short)(g & 0xffff), gx2 = g >> 16;
+        w.s_gk[row * L::RS + col] = make_uint2((uint32_t)(gy2 * gy2 + gx2 * gx2) << 10, (uint32_t)g);
     }
 }
 
@@ -255,6 +289,8 @@ __device__ __forceinline__ void step_far(const Params& p, const int b, const Des
 template <int PT>
 __device__ __forceinline__ void step_near(const Params& p, const int b, const Desc* __restrict__ d, const int nblock,
                                           unsigned char* smem) {
+    // the near block that also copies the pixels: the last one, whose four waves share a single tile
+    constexpr int COPY_BLOCK = (CRIM_NEAR_TILES + 3) / 4 - 1;
     constexpr int GR = PT + 4;       // grey region: the patch grown by two pixels
     constexpr int NG = PT + 2;       // gradient region: the patch grown by one pixel
     __shared__ double s_c[4];
@@ -266,8 +302,9 @@ __device__ __forceinline__ void step_near(const Params& p, const int b, const De
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int H = p.H, W = p.W, half = p.half;
     const size_t HW = (size_t)H * W;
-    const long long t_entry = (nblock == 0 && tid == 0) ? (long long)wall_clock64() : 0;
+    const long long t_entry = (nblock == COPY_BLOCK && tid == 0) ? (long long)wall_clock64() : 0;
 
+    STAMP_AT(1, 40);
     // Load batch 1: the search's per-block results (as k_update reads them) and the descriptor.
     const SEntry* sl = p.nparts > 0 ? p.xchg : p.slist + (size_t)b * p.snx * p.sny;
     const int scols = p.nparts > 0 ? p.nparts : p.scols;
@@ -278,14 +315,25 @@ __device__ __forceinline__ void step_near(const Params& p, const int b, const De
     SEntry spec[NSPEC];
 #pragma unroll
     for (int k = 0; k < NSPEC; ++k) spec[k] = sl[slot_of(tid + 256 * k)];
+    uint8_t kf = 1;
+    if (tid < PT * PT) kf = d->kflat[tid];
+    const int live = d->live;   // written by this iteration's search launch
     const int ncx = d->ncx;
     const int grows = p.nparts > 0 ? 1 : (d->ncy + SB_H - 1) / SB_H;
     const int gcols = p.nparts > 0 ? p.nparts : search_cols(p, ncx);
     const int n = grows * scols;
     const int r0 = d->r0, c0 = d->c0, ph = d->ph, pw = d->pw;
     const int cur = d->cur;
-    uint8_t kf = 1;
-    if (tid < PT * PT) kf = d->kflat[tid];
+    // (everything the block needs from the descriptor is read here, in one batch of scalar loads: a read
+    // further down would cost the chain a round trip of its own)
+    const double cnew = d->cnew;
+    const int d_tr = d->tr, d_tc = d->tc, d_iter = d->iter, d_rem = d->remaining - d->nfill;
+    const long long d_tsel = d->t_select;
+    if (!live) return;
+    // this wave's LDS working set, and the offset table of the fast path, while the loads travel
+    PrioLds<PT> L;
+    L.carve(smem + (size_t)wv * p.plds);
+    L.fill_offsets(lane);
 
     uint8_t* mask = p.mask + b * HW;
     uint8_t* bgr = p.bgr + b * HW * 3;
@@ -354,24 +402,42 @@ __device__ __forceinline__ void step_near(const Params& p, const int b, const De
     // no admissible window: every cost is +inf and np.argmin returns index 0
     const unsigned src = (bi == 0xffffffffu) ? 0u : bi;
     const int sy = (int)(src / (unsigned)ncx), sx = (int)(src % (unsigned)ncx);
+    STAMP_AT(1, 41);
 
-    // Load batch 3 (needs the source position): the source pixels (block 0: all of a pixel; the others
-    // only need the grey value).
-    for (int e = tid; e < ph * pw; e += 256) {
-        const int i = e / pw, j = e - i * pw;
-        const size_t s = (size_t)(sy + i) * W + sx + j;
-        if (nblock == 0) {
-            const size_t so = (size_t)(sy + i) * p.Wp + sx + j;
-            uint8_t v[4 + CRIM_NPL];
-            v[0] = bgr[3 * s]; v[1] = bgr[3 * s + 1]; v[2] = bgr[3 * s + 2];
+    // Load batch 3 (needs the source position): the source pixels, one per thread (the copying block: all
+    // of a pixel; the others only need the grey value).  Requested now, used further down.
+    static_assert(PT * PT <= 256, "one source pixel per thread");
+    const bool has_src = tid < ph * pw;
+    const int si = has_src ? tid / pw : 0, sj = has_src ? tid - si * pw : 0;
+    uint8_t sv[4 + CRIM_NPL];
+    {
+        const size_t s = (size_t)(sy + si) * W + sx + sj;
+        if (nblock == COPY_BLOCK) {
+            const size_t so = (size_t)(sy + si) * p.Wp + sx + sj;
+            sv[0] = bgr[3 * s]; sv[1] = bgr[3 * s + 1]; sv[2] = bgr[3 * s + 2];
 #pragma unroll
-            for (int k = 0; k < CRIM_NPL; ++k) v[3 + k] = planes[k * PS + so];
-            v[3 + CRIM_NPL] = grey[s];
-#pragma unroll
-            for (int k = 0; k < 4 + CRIM_NPL; ++k) s_px[e][k] = v[k];
-        } else {
-            s_px[e][3 + CRIM_NPL] = grey[s];
+            for (int k = 0; k < CRIM_NPL; ++k) sv[3 + k] = planes[k * PS + so];
         }
+        sv[3 + CRIM_NPL] = grey[s];
+    }
+    // ---- while those travel: this wave's tile of the next iteration's priority stage is staged with
+    // what of the update is known already (mask cleared inside the patch, confidence of the filled
+    // pixels) and its front pixels are listed
+    PatchOverride ov;
+    ov.r0 = r0; ov.c0 = c0; ov.ph = ph; ov.pw = pw; ov.cnew = cnew; ov.kflat = s_kf; ov.ngrad = s_ng;
+    int nf = 0;
+    if (active) {
+        tile_commit<PT, true, true>(p, stg, L, ov, lane);
+        wave_lds_sync();
+        nf = tile_front_list<PT>(p, L, stg.ty0, stg.tx0, lane);
+    }
+    STAMP_AT(1, 44);
+    if (has_src) {
+        if (nblock == COPY_BLOCK) {
+#pragma unroll
+            for (int k = 0; k < 4 + CRIM_NPL; ++k) s_px[tid][k] = sv[k];
+        }
+        if (s_kf[si * PT + sj] == 0) s_g[(si + 2) * GR + (sj + 2)] = sv[3 + CRIM_NPL];
     }
     // grey around the patch as the gradient sees it after the fill: 0 on pixels still masked (the patch
     // itself is cleared), the source's grey on filled pixels
@@ -383,16 +449,13 @@ __device__ __forceinline__ void step_near(const Params& p, const int b, const De
         const int yy = gr0 + i, xx = gc0 + j;
         const int pi = i - 2, pj = j - 2;
         const bool inpatch = pi >= 0 && pi < ph && pj >= 0 && pj < pw;
+        if (inpatch && s_kf[pi * PT + pj] == 0) continue;   // filled: written above, from the source
         uint8_t v = 0;
         if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = (gm[k] && !inpatch) ? (uint8_t)0 : gg[k];
         s_g[i * GR + j] = v;
     }
     __syncthreads();
-    for (int e = tid; e < ph * pw; e += 256) {
-        const int i = e / pw, j = e - i * pw;
-        if (s_kf[i * PT + j] == 0) s_g[(i + 2) * GR + (j + 2)] = s_px[e][3 + CRIM_NPL];
-    }
-    __syncthreads();
+    STAMP_AT(1, 42);
     // ---- gradient within one pixel of the patch (np.gradient, :174)
     const int uh = ph + 2, uw = pw + 2;
     for (int e = tid; e < uh * uw; e += 256) {
@@ -411,11 +474,11 @@ __device__ __forceinline__ void step_near(const Params& p, const int b, const De
             else if (xx == W - 1) gx2 = 2 * (G(yy, xx) - G(yy, xx - 1));
             else gx2 = G(yy, xx + 1) - G(yy, xx - 1);
             pk = (gy2 & 0xffff) | (int)((unsigned)gx2 << 16);
-            if (nblock == 0) grad[(size_t)yy * W + xx] = pk;
+            if (nblock == COPY_BLOCK) grad[(size_t)yy * W + xx] = pk;
         }
         s_ng[i * NG + j] = pk;
     }
-    if (nblock == 0) {
+    if (nblock == COPY_BLOCK) {
         // ---- the copy itself (:287-296): masked pixels of the target patch take the source's
         for (int e = tid; e < ph * pw; e += 256) {
             const int i = e / pw, j = e - i * pw;
@@ -429,35 +492,32 @@ __device__ __forceinline__ void step_near(const Params& p, const int b, const De
             grey[q] = s_px[e][3 + CRIM_NPL];
         }
         if (tid == 0) {
-            const int it = d->iter;
+            const int it = d_iter;
             if (p.trace && it < p.trace_cap) {
                 crim_iter_rec rec;
-                rec.tr = d->tr; rec.tc = d->tc; rec.sy = sy; rec.sx = sx;
-                rec.cost = bc; rec.remaining = d->remaining - d->nfill;
+                rec.tr = d_tr; rec.tc = d_tc; rec.sy = sy; rec.sx = sx;
+                rec.cost = bc; rec.remaining = d_rem;
                 p.trace[(size_t)b * p.trace_cap + it] = rec;
-                if (p.stime) p.stime[(size_t)b * p.trace_cap + it] = (float)(t_entry - d->t_select) * 0.01f;
+                if (p.stime) p.stime[(size_t)b * p.trace_cap + it] = (float)(t_entry - d_tsel) * 0.01f;
             }
         }
     }
     __syncthreads();   // s_ng is complete
+    STAMP_AT(1, 43);
 
-    // ---- this wave's tile of the next iteration's priority stage, staged with the update applied
+    // ---- the staged gradient gets the update's part, then the front pixels are evaluated
     double bestP = -1.0;
     int bestI = 0x7fffffff;
     if (active) {
-        PrioLds<PT> L;
-        L.carve(smem + (size_t)wv * p.plds);
-        L.fill_offsets(lane);
-        PatchOverride ov;
-        ov.r0 = r0; ov.c0 = c0; ov.ph = ph; ov.pw = pw; ov.cnew = d->cnew; ov.kflat = s_kf; ov.ngrad = s_ng;
-        tile_commit<PT, true, true>(p, stg, L, ov, lane);
+        tile_patch_gradient<PT>(p, stg.ty0, stg.tx0, L, ov, lane);
         wave_lds_sync();
-        const int nf = tile_front_list<PT>(p, L, stg.ty0, stg.tx0, lane);
-        wave_lds_sync();
+        STAMP_AT(1, 45);
         prio_eval_tile<PT>(p, L.s_cf, L.s_gk, L.s_list, L.s_mask, L.s_off, PrioLds<PT>::RS, stg.ty0, stg.tx0, nf, true,
                            p.dterm + b * HW, cwrite, lane / PG, lane % PG, bestP, bestI);
     }
+    STAMP_AT(1, 46);
     if (t < CRIM_NEAR_TILES) emit_priority(p, b, t, bestP, bestI, lane);
+    STAMP_AT(1, 47);
 }
 
 // ---- bookkeeping -------------------------------------------------------------------------------
@@ -474,13 +534,15 @@ __device__ __forceinline__ void step_book(const Params& p, const int b, const De
     __shared__ uint8_t s_m0[MR * MR];   // the same before it
     __shared__ unsigned s_fill[(PM * PM + 31) / 32];        // bit e: patch element e is filled
     __shared__ unsigned s_fnew[((PM + 2) * (PM + 2) + 31) / 32];   // bit e: element e of the patch grown by one is on the next front
-    __shared__ unsigned long long s_rb[MR][2];
-    __shared__ unsigned long long s_rw[MR][2];
+    static_assert(MR <= 64, "a row of the mask snapshot fits one 64-bit word (patch edges up to 21)");
+    __shared__ unsigned long long s_rb[MR];            // per snapshot row: bit j = pixel j masked
+    __shared__ unsigned long long s_rw[MR];            // OR of P consecutive rows
     __shared__ int s_ovf;
     __shared__ unsigned s_tw[4];
     __shared__ int s_td[9];
     __shared__ unsigned s_napp;
 
+    STAMP_AT(0, 48);
     // loop state: this block is its only reader and writer during the launch
     const int cur = st->cur;
     const int remaining0 = st->remaining, iter0 = st->iter;
@@ -538,6 +600,7 @@ __device__ __forceinline__ void step_book(const Params& p, const int b, const De
     if (tid < (PM * PM + 31) / 32) s_fill[tid] = 0;
     if (tid < ((PM + 2) * (PM + 2) + 31) / 32) s_fnew[tid] = 0;
     __syncthreads();
+    STAMP_AT(0, 49);
 
     // ---- the masked pixels of the target patch: confidence (:274-284) and mask (:299-308)
     for (int e0 = 0; e0 < ph * pw; e0 += 256) {
@@ -559,6 +622,7 @@ __device__ __forceinline__ void step_book(const Params& p, const int b, const De
         }
     }
 
+    STAMP_AT(0, 50);
     // ---- window-validity maps: origins whose P x P window touches the patch (as k_update)
     uint8_t* inv = p.invalid + (size_t)b * H * p.Wi;
     const int oh = ph + P - 1, ow = pw + P - 1;
@@ -567,15 +631,15 @@ __device__ __forceinline__ void step_book(const Params& p, const int b, const De
         const int lane = tid & 63, wave = tid >> 6;
         for (int row = wave; row < mrh; row += 4) {
             const unsigned long long lo = __ballot(lane < mrw && s_m[row * MR + lane]);
-            const unsigned long long hi = __ballot(64 + lane < mrw && s_m[row * MR + 64 + lane]);
-            if (lane == 0) { s_rb[row][0] = lo; s_rb[row][1] = hi; }
+            if (lane == 0) s_rb[row] = lo;
         }
     }
     __syncthreads();
     for (int i = tid; i < oh; i += 256) {
-        unsigned long long lo = 0, hi = 0;
-        for (int a = 0; a < P; ++a) { lo |= s_rb[og + i + a][0]; hi |= s_rb[og + i + a][1]; }
-        s_rw[i][0] = lo; s_rw[i][1] = hi;
+        unsigned long long lo = 0;
+#pragma unroll
+        for (int a = 0; a < PM; ++a) lo |= s_rb[og + i + a];   // P == PM in this kernel
+        s_rw[i] = lo;
     }
     __syncthreads();
     {
@@ -586,14 +650,9 @@ __device__ __forceinline__ void step_book(const Params& p, const int b, const De
             const bool in = lane < ow && oy >= 0 && ox >= 0 && oy <= H - P && ox <= W - P;
             bool bad = true;
             if (in) {
-                const int sft = og + lane;
-                const unsigned long long lo = s_rw[i][0], hi = s_rw[i][1];
-                unsigned long long w;
-                if (sft == 0) w = lo;
-                else if (sft < 64) w = (lo >> sft) | (hi << (64 - sft));
-                else w = hi >> (sft - 64);
+                const int sft = og + lane;                 // < MR <= 64
                 const unsigned long long pm = (1ull << P) - 1ull;
-                bad = (w & pm) != 0;
+                bad = ((s_rw[i] >> sft) & pm) != 0;
                 inv[(size_t)oy * p.Wi + ox] = (uint8_t)bad;
             }
             const unsigned long long good = __ballot(in && !bad);
@@ -608,6 +667,7 @@ __device__ __forceinline__ void step_book(const Params& p, const int b, const De
             }
         }
     }
+    STAMP_AT(0, 51);
     // ---- per-tile front counts (pixels within one pixel of the patch), and which of those pixels are
     // on the next iteration's front
     {
@@ -648,6 +708,7 @@ __device__ __forceinline__ void step_book(const Params& p, const int b, const De
             }
         }
     }
+    STAMP_AT(0, 52);
     // ---- confidence buffers: the buffer that was current during this iteration is stale on this
     // iteration's front and patch.  The pixels of the NEXT front are being rewritten by this launch's
     // priority waves (they must not be touched here); every other stale pixel lies within one pixel of
@@ -711,6 +772,7 @@ __device__ __forceinline__ void step_book(const Params& p, const int b, const De
         if (rem <= 0) st->live = 0;
         else if (nf == 0) { st->live = 0; st->stalled = 1; }
     }
+    STAMP_AT(0, 53);
 }
 
 template <int P>
@@ -720,8 +782,12 @@ __global__ __launch_bounds__(256) void k_step(Params p) {
     xcd_decode(blockIdx.x, p.kblocks, p.B, &img_, &sub);
     const int b = p.b0 + img_;
     const Desc* __restrict__ d = p.desc + b;
+    // (the near blocks request the search's results before they look at anything else)
+    if (sub >= 1 && sub <= (CRIM_NEAR_TILES + 3) / 4) {
+        step_near<P>(p, b, d, sub - 1, smem);
+        return;
+    }
     if (!d->live) return;   // written by this iteration's search launch
     if (sub == 0) step_book<P>(p, b, d);
-    else if (sub <= (CRIM_NEAR_TILES + 3) / 4) step_near<P>(p, b, d, sub - 1, smem);
     else step_far<P>(p, b, d, sub - 1 - (CRIM_NEAR_TILES + 3) / 4, smem);
 }

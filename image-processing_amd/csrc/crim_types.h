@@ -108,6 +108,7 @@ struct Params {
     int dmax;     // upper bound of the distance term of the search cost: ceil(sqrt(H^2 + W^2)) + 1
     int mgx, mrows; // matrix-core search launch: blocks per row of tiles, rows of tiles covered
     int mtiles, mchunks; // pipelined matrix-core search: rows of tiles per block, blocks per column of tiles
+    int pipe_force;   // host side: > 0 fixes the rows of tiles per block (experiments)
     int pipe_t, pipe_min_blocks; // host side: most rows of tiles per block (0 = plain kernel), launch size below which fewer are used
     int nparts;   // > 0: split search, k_update reduces xchg[0..nparts) instead of the partial list
     int pgrid;    // priority slots per image: one per wave of the priority stage

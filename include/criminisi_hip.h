@@ -133,15 +133,19 @@ int crim_download_device(crim_t* h, int first, int count, void* d_bgr_out);
  * for ONE image, without allocating anything.  No counterpart in the reference; it is for callers
  * that cannot allocate device memory while they run (tight serving loops, harnesses that forbid
  * hipMalloc): all engine state, including the partial results of the priority and search stages,
- * lives in one static device array of 44 * CRIM_NOALLOC_MAX_PIXELS + 256 KiB bytes (11.3 MiB)
- * that each GPU the library runs on holds until the process ends.  d_bgr ([H][W][3]), d_mask
+ * lives in one static device array of CRIM_NOALLOC_BYTES (52 bytes per pixel of the largest image
+ * + 256 KiB = 13.25 MiB) that each GPU the library runs on holds until the process ends.  d_bgr ([H][W][3]), d_mask
  * ([H][W], nonzero = fill) and d_bgr_out ([H][W][3]) are dense device buffers on GPU `device`.
- * H * W must not exceed CRIM_NOALLOC_MAX_PIXELS (every such shape with W >= 32 fits; narrower
- * images may be refused because their plane rows are padded): CRIM_ERR_ARG otherwise.  Work is
+ * H * W must not exceed CRIM_NOALLOC_MAX_PIXELS (every such shape with H >= 32 and W >= 32 fits;
+ * narrower or flatter images may be refused because their plane rows are padded and the planes end in
+ * 64 spare rows; crim_noalloc_bytes_needed tells): CRIM_ERR_ARG otherwise.  Work is
  * issued on the default stream and the call returns when the result is in d_bgr_out.  Calls for
  * one GPU share that GPU's array: the library serialises them within a process (a lock per GPU);
  * calls from different handles of crim_create are independent of it.  No per-iteration records. */
 #define CRIM_NOALLOC_MAX_PIXELS (512 * 512)
+#define CRIM_NOALLOC_BYTES ((size_t)52 * CRIM_NOALLOC_MAX_PIXELS + ((size_t)1 << 18))
+/* Bytes of that array a call for this shape would use (0 for a bad argument); needs no GPU. */
+size_t crim_noalloc_bytes_needed(int H, int W, int patch_size);
 int crim_inpaint_noalloc(int H, int W, int patch_size, int device, const void* d_bgr,
                          const void* d_mask, void* d_bgr_out, long* iters_done);
 
@@ -162,6 +166,12 @@ int crim_filter_noise_engine(crim_t* h, int median_ksize, float nlm_h, int apply
 int crim_trace(crim_t* h, int index, crim_iter_rec* buf, long cap, long* n);
 /* Iterations executed so far by image `index`. */
 int crim_iterations(crim_t* h, int index, long* n);
+/* 'Time to find best' of every executed iteration of image `index` (the reference times
+ * _find_source_patch per iteration with time.time(), :64-69): microseconds from the end of the target
+ * selection to the start of the update on the device's 100 MHz clock, i.e. the search launch and the
+ * launch boundary after it; lock-step batches share the launch, so every image of a batch sees its
+ * batch's time.  Kept with the per-iteration records (none under CRIM_FLAG_NO_TRACE). */
+int crim_search_times(crim_t* h, int index, float* us_out, long cap, long* n);
 
 /* The integer BGR->Lab tables the engine uses in place of cv2.cvtColor(..., COLOR_BGR2LAB)
  * (:225): 256-entry sRGB gamma table, 3072-entry cube-root table, 9 matrix coefficients
@@ -177,6 +187,20 @@ int crim_profile(crim_t* h, double* search_ms, long* search_launches, double* ev
  * skipped. */
 int crim_peek_fields(crim_t* h, int index, uint8_t* front_out, double* data_out,
                      double* priority_out);
+
+/* ---- debug / parity instruments (used by the test-suite; no counterpart in the reference) ---------- */
+/* Raw copy of image `index`'s loop state: 16 ints (iter, live, cur, remaining, tile-list length, chroma,
+ * two unused, stalled, pruning bound, tile-list rebuilds, tile-list buffer, ...). */
+int crim_debug_state(crim_t* h, int index, int* out16);
+/* Pads image `index`'s tile list to its capacity with copies of its first entry, so that the next
+ * appended tile finds the list full and the in-kernel rebuild has to run. */
+int crim_debug_fill_tile_list(crim_t* h, int index);
+/* The cached data terms of image `index` (H*W doubles; meaningful only at pixels that were on the front
+ * when the priority stage last evaluated their tile). */
+int crim_debug_dterm(crim_t* h, int index, double* out);
+/* The 64 named time-stamp slots of the iteration kernels (zeros unless the library was built with
+ * -DCRIM_STAMPS). */
+int crim_debug_stamps(crim_t* h, long long* out64);
 
 #ifdef __cplusplus
 }

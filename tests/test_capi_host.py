@@ -107,3 +107,23 @@ def test_shim_warns_beyond_the_exact_regime_of_the_reference():
         assert not w
         Criminisi_Inpainter(img, mask, patch_size=17)
         assert len(w) == 1 and "float32" in str(w[0].message)
+
+
+def test_noalloc_state_fits_its_static_array_for_every_promised_shape():
+    """crim_inpaint_noalloc carves all engine state of one image out of a static device array of
+    CRIM_NOALLOC_BYTES; the header promises room for every shape of at most 512 * 512 pixels with at least
+    32 rows and 32 columns.  The layout is computed on the host, so the promise is checked here for
+    the extreme shapes and every patch size (a plane added to the engine state shows up in this test,
+    not as a refused call)."""
+    lib = capi.load_library()
+    worst = 0
+    for h, w in ((512, 512), (8192, 32), (32, 8192), (1024, 256), (256, 1024), (511, 513), (64, 4096), (4096, 64)):
+        assert h * w <= capi.NOALLOC_MAX_PIXELS
+        for patch in (1, 3, 9, 15, 16, 31):
+            need = capi.noalloc_bytes_needed(h, w, patch)
+            assert 0 < need <= capi.NOALLOC_BYTES, (h, w, patch, need)
+            worst = max(worst, need)
+    assert worst > 0.8 * capi.NOALLOC_BYTES      # the constant is not a wild over-estimate either
+    # a single row of 262144 pixels is refused: the search planes end in 64 spare rows of that width
+    assert capi.noalloc_bytes_needed(1, 262144, 9) > capi.NOALLOC_BYTES
+    assert capi.noalloc_bytes_needed(0, 5, 9) == 0 and lib.crim_noalloc_bytes_needed(5, 5, 99) == 0

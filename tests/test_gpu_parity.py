@@ -371,6 +371,56 @@ def _debug_state(eng, index=0):
     return list(buf)
 
 
+@pytest.mark.parametrize("p,off", [(9, 0), (9, 1), (9, -1), (9, 4), (9, 5), (9, -5), (9, 6), (15, 0), (15, 7), (15, 8),
+                                   (15, -8), (3, 0), (3, 2), (5, -3), (13, 9)])
+def test_target_patches_next_to_far_tiles(p, off):
+    """Single images run two launches per iteration: the search, and one launch that updates the image AND
+    evaluates the next iteration's priorities -- tiles within the patch half-width + 1 of the filled patch
+    ("near") from the update applied on the fly, all others ("far") from memory, concurrently with the
+    update.  Holes whose edges sit on, and a few pixels either side of, the 16-pixel tile grid put target
+    patches right at the boundary between the two kinds, in every direction; a second hole keeps far tiles
+    with a live front around for the whole run."""
+    H, W = 112, 128
+    img = crim_synth.xray_like(H, W, 7300 + 10 * p + off, colour=True)
+    m = np.zeros((H, W), np.uint8)
+    m[32 + off:64 + off, 48 + off:96 + off] = 1      # edges on the tile grid shifted by `off`
+    m[80:96, 16:32] = 1                              # exactly one tile
+    m[18:26, 100:118] = 1
+    assert_same_as_oracle(img, m, p)
+
+
+@pytest.mark.parametrize("p,colour,border", [(9, True, False), (15, True, True), (5, False, True), (9, False, False),
+                                             (3, True, True), (7, True, False), (11, False, False), (13, True, True)])
+def test_three_launch_iteration_still_matches(p, colour, border, monkeypatch):
+    """CRIM_FUSED=0: the iteration as priority, search (which also selects), update -- the graph that
+    batches beyond the two-launch regime replay -- on single images."""
+    monkeypatch.setenv("CRIM_FUSED", "0")
+    img, m = rand_case(640 + p, 80, 104, noise=False, colour=colour, border=border)
+    assert_same_as_oracle(img, m, p)
+
+
+def test_two_launch_iteration_on_a_batch_with_stepping():
+    """A small batch (two-launch iterations), images finishing at different times, advanced a few
+    iterations per call: every call starts with a full priority launch that must leave the state as the
+    previous call's last launch already computed it."""
+    H, W, B = 80, 96, 6
+    imgs = np.stack([crim_synth.xray_like(H, W, 7400 + i, colour=(i % 3 != 0)) for i in range(B)])
+    masks = np.stack([crim_synth.blob_mask(H, W, 7400 + i, fraction=0.03 + 0.02 * i, margin=9) for i in range(B)])
+    masks[2] = 0
+    with capi.Engine(H, W, 9, batch=B) as eng:
+        eng.upload(imgs, masks)
+        rem, calls = 1, 0
+        while rem:
+            _, rem = eng.run(max_iters=1 + calls % 5)
+            calls += 1
+        out, conf, _ = eng.download(want_conf=True)
+        traces = [eng.trace(i) for i in range(B)]
+    for i in range(B):
+        oout, oconf, _, otr, n = c_oracle.run(imgs[i], masks[i], 9)
+        assert np.array_equal(traces[i], otr.astype(capi.ITER_REC_DTYPE)), i
+        assert np.array_equal(out[i], oout) and np.array_equal(conf[i], oconf), i
+
+
 @pytest.mark.parametrize("stepwise", [True, False])
 def test_tile_list_outgrowing_its_capacity_is_rebuilt(stepwise):
     """A hole that covers whole 16x16 tiles: their front counts leave zero only when the fill
@@ -480,11 +530,20 @@ def test_shim_verbose_and_show_progress_side_effects(tmp_path, monkeypatch, caps
     oout, _, _, otr, n = c_oracle.run(img, m, 9)
     total = int(m.sum())
     monkeypatch.setattr(Criminisi_Inpainter, "VERBOSE_CHUNK", 3)
-    out = Criminisi_Inpainter(img, m, patch_size=9, verbose=True).inpaint()
+    import time
+    t0 = time.time()
+    ip = Criminisi_Inpainter(img, m, patch_size=9, verbose=True)
+    out = ip.inpaint()
+    wall = time.time() - t0
     assert np.array_equal(out, oout)
     lines = capsys.readouterr().out.splitlines()
     assert len(lines) == 2 * n + 1
     assert all(l.startswith('Time to find best: ') and l.endswith(' seconds') for l in lines[0:-1:2])
+    # 'Time to find best' is each iteration's own search time as the device measured it (:64-69): one value
+    # per iteration, positive, not all alike, together no more than the run took
+    ts = ip.search_seconds
+    assert ts is not None and len(ts) == n
+    assert (ts > 0).all() and ts.sum() <= wall and len(set(np.round(ts * 1e8).astype(np.int64))) > 1
     assert lines[1:-1:2] == ['%d of %d completed' % (total - int(r), total) for r in otr['remaining']]
     assert lines[-1].startswith('Inpainting took ')
     monkeypatch.chdir(tmp_path)
@@ -581,6 +640,35 @@ def test_512_prefix_and_properties():
     # every source window was free of masked pixels and inside the image
     assert tr["sy"].min() >= 0 and tr["sx"].min() >= 0
     assert tr["sy"].max() <= 512 - 9 and tr["sx"].max() <= 512 - 9
+
+
+def test_512_batch_prefix_per_image():
+    """BASELINE configs[2] as a BATCH: 16 false-colour 512x512 images with different 10 % masks in lock
+    step (two lanes), the first iterations of every image against the oracle record for record, then the
+    whole batch to completion through properties that need no oracle."""
+    B, S, iters = 16, 512, 5
+    imgs = np.stack([crim_synth.xray_like(S, S, 3000 + i, colour=True) for i in range(B)])
+    masks = np.stack([crim_synth.blob_mask(S, S, 3000 + i, fraction=0.10, margin=9) for i in range(B)])
+    with capi.Engine(S, S, 9, batch=B) as eng:
+        eng.upload(imgs, masks)
+        eng.run(max_iters=iters)
+        out, conf, msk = eng.download(want_conf=True, want_mask=True)
+        traces = [eng.trace(i) for i in range(B)]
+        for i in range(B):
+            oout, oconf, omask, otr, n = c_oracle.run(imgs[i], masks[i], 9, max_iters=iters)
+            assert np.array_equal(traces[i][:n], otr.astype(capi.ITER_REC_DTYPE)), i
+            assert np.array_equal(out[i], oout) and np.array_equal(conf[i], oconf) and np.array_equal(msk[i], omask), i
+        it, rem = eng.run()
+        out, conf, msk = eng.download(want_conf=True, want_mask=True)
+        counts = [eng.iterations(i) for i in range(B)]
+        traces = [eng.trace(i) for i in range(B)]
+    assert rem == 0 and not msk.any() and len(set(counts)) > 1          # images finish at different times
+    for i in range(B):
+        assert np.array_equal(out[i][masks[i] == 0], imgs[i][masks[i] == 0])
+        assert (np.diff(traces[i]["remaining"]) < 0).all() and traces[i]["remaining"][-1] == 0
+        assert (conf[i] > 0).all() and (conf[i] <= 1).all()
+        want, _ = c_oracle.replay(imgs[i], masks[i], 9, traces[i], len(traces[i]))
+        assert np.array_equal(out[i], want), i
 
 
 @pytest.mark.parametrize("p,iters", [(9, 4), (15, 2)])

@@ -17,7 +17,7 @@ lib.crim_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 if H > 256:   # one large image with a centred square hole, as BASELINE configs[3] / [4]
     imgs = crim_synth.xray_like(H, W, 4000 + H, colour=True)[None]
     masks = crim_synth.square_hole_mask(H, W, H // 2)[None]
-eng = capi.Engine(H, W, 9, batch=B, flags=capi.FLAG_EAGER)
+eng = capi.Engine(H, W, 9, batch=B, flags=0 if os.environ.get("STAMPS_GRAPH") else capi.FLAG_EAGER)
 eng.upload(imgs, masks)
 eng.run(max_iters=40)
 acc = {}
@@ -28,6 +28,9 @@ for it in range(20):
         v = st[list(slots)]
         d = np.diff(v) * 10  # ns (100 MHz)
         acc.setdefault(name, []).append(d)
+    acc.setdefault("step near block 0 (entry, arg-min, source pixels, gradient, commit, front list, evaluation, emit)", []).append(np.diff(st[40:48]) * 10)
+    acc.setdefault("step bookkeeping (entry, snapshot, fill, validity, tile counts, refresh+state)", []).append(np.diff(st[48:54]) * 10)
+    acc.setdefault("search entry -> near entry -> book end", []).append(np.array([st[40] - st[32], st[53] - st[40], st[47] - st[40]]) * 10)
     acc.setdefault("gaps priority->search, search->update, update->next priority", []).append(np.array([st[32] - st[3], st[16] - st[38], 0]) * 10)
 for k, v in acc.items():
     print(k, "mean ns per phase:", np.mean(v, axis=0).astype(int).tolist(), "total", int(np.mean(np.sum(v, axis=1))))
