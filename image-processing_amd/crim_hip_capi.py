@@ -78,6 +78,10 @@ def load_library():
     lib.crim_split_unique_id.argtypes = [vp]
     lib.crim_split_init.restype = ci
     lib.crim_split_init.argtypes = [vp, ci, ci, vp]
+    lib.crim_split_init_host.restype = ci
+    lib.crim_split_init_host.argtypes = [vp, ci, ci, ctypes.c_char_p]
+    lib.crim_split_status.restype = ci
+    lib.crim_split_status.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(cl)]
     lib.crim_split_info.restype = ci
     lib.crim_split_info.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci)]
     lib.crim_run.restype = ci
@@ -288,6 +292,17 @@ class Engine:
     def split_init(self, nranks, rank, unique_id):
         buf = ctypes.create_string_buffer(bytes(unique_id), 128)
         _check(load_library().crim_split_init(self._h, int(nranks), int(rank), buf))
+
+    def split_init_host(self, nranks, rank, shared_file):
+        """This process scores part `rank` of `nranks`; the ranks' processes (on one host) exchange their
+        records through the file-backed mapping `shared_file` (a fresh path every rank passes)."""
+        _check(load_library().crim_split_init_host(self._h, int(nranks), int(rank), os.fsencode(shared_file)))
+
+    def split_status(self):
+        """(iterations replayed from captured graphs?, records exchanged through host memory so far)."""
+        g, n = ctypes.c_int(), ctypes.c_long()
+        _check(load_library().crim_split_status(self._h, ctypes.byref(g), ctypes.byref(n)))
+        return bool(g.value), n.value
 
     def split_info(self):
         """(ranks, rank) as the RCCL communicator reports them."""

@@ -52,16 +52,19 @@ def wait_for_file(path, timeout_s, poll_s=0.05):
 
 
 def launch_worker(rank, world, device, rendezvous, size=4096, patch=9, iters=2000, dry_run=False,
-                  python=None):
-    """Starts this module as a child process for one rank; returns the Popen object."""
+                  python=None, transport="rccl", dump_trace=False, wait=900.0):
+    """Starts this module as a child process for one rank; returns the Popen object (its log file is
+    closed in this process once the child holds it)."""
     os.makedirs(rendezvous, exist_ok=True)
     cmd = [python or sys.executable, os.path.abspath(__file__), "--rank", str(rank), "--world", str(world),
            "--device", str(device), "--rendezvous", rendezvous, "--size", str(size), "--patch", str(patch),
-           "--iters", str(iters)]
+           "--iters", str(iters), "--transport", transport, "--wait", str(wait)]
     if dry_run:
         cmd.append("--dry-run")
-    log = open(os.path.join(rendezvous, "worker.%d.log" % rank), "wb")
-    return subprocess.Popen(cmd, stdout=log, stderr=subprocess.STDOUT, cwd=ROOT)
+    if dump_trace:
+        cmd.append("--dump-trace")
+    with open(os.path.join(rendezvous, "worker.%d.log" % rank), "wb") as log:
+        return subprocess.Popen(cmd, stdout=log, stderr=subprocess.STDOUT, cwd=ROOT)
 
 
 def release(rendezvous):
@@ -109,6 +112,11 @@ def main():
     ap.add_argument("--iters", type=int, default=2000)
     ap.add_argument("--dry-run", action="store_true")
     ap.add_argument("--wait", type=float, default=900.0, help="seconds to wait for the go file")
+    ap.add_argument("--transport", choices=("rccl", "host"), default="rccl",
+                    help="how the ranks exchange their records: RCCL all-gather, or host memory shared by the "
+                         "ranks' processes (tests; ranks that share one GPU)")
+    ap.add_argument("--dump-trace", action="store_true",
+                    help="save this rank's per-iteration records of the split run as trace.<rank>.npy")
     args = ap.parse_args()
     rdv, rank, world = args.rendezvous, args.rank, args.world
     res = {"rank": rank, "world": world, "size": args.size, "patch": args.patch, "iterations": args.iters}
@@ -133,7 +141,7 @@ def main():
         # id exchange
         idpath = os.path.join(rdv, "id")
         if rank == 0:
-            uid = os.urandom(128) if args.dry_run else capi.split_unique_id()
+            uid = os.urandom(128) if (args.dry_run or args.transport == "host") else capi.split_unique_id()
             write_atomic(idpath, uid)
         else:
             uid = wait_for_file(idpath, 120.0)
@@ -147,26 +155,35 @@ def main():
             res["rccl_ranks"] = world
             finish(0)
 
-        def timed(eng):
+        def timed(eng, dump=None):
             eng.upload(img, mask)
             eng.run(max_iters=32)
             t = time.perf_counter()
             eng.run(max_iters=args.iters)
             dt = time.perf_counter() - t
             tr = eng.trace(0)
+            if dump:
+                np.save(dump, tr)
             sig = int(np.bitwise_xor.reduce(tr["sy"].astype(np.int64) * 65536 + tr["sx"]))
             return 1e6 * dt / args.iters, sig
 
         with capi.Engine(S, S, args.patch, device=args.device) as eng:
             if rank == 0:
                 res["single_gpu_us_per_iteration"], res["single_gpu_trace_signature"] = timed(eng)
-            eng.split_init(world, rank, uid)
-            n_seen, r_seen = eng.split_info()
-            res["rccl_ranks"] = n_seen
-            if n_seen != world or r_seen != rank:
-                res["error"] = "RCCL reports rank %d of %d, expected %d of %d" % (r_seen, n_seen, rank, world)
-                finish(5)
-            res["us_per_iteration"], res["trace_signature"] = timed(eng)
+            res["transport"] = args.transport
+            if args.transport == "host":
+                eng.split_init_host(world, rank, os.path.join(rdv, "exchange." + hashlib.sha1(uid).hexdigest()[:12]))
+                res["rccl_ranks"] = None
+            else:
+                eng.split_init(world, rank, uid)
+                n_seen, r_seen = eng.split_info()
+                res["rccl_ranks"] = n_seen
+                if n_seen != world or r_seen != rank:
+                    res["error"] = "RCCL reports rank %d of %d, expected %d of %d" % (r_seen, n_seen, rank, world)
+                    finish(5)
+            res["us_per_iteration"], res["trace_signature"] = timed(
+                eng, os.path.join(rdv, "trace.%d.npy" % rank) if args.dump_trace else None)
+            res["graph_captured"], res["host_exchanges"] = eng.split_status()
         if rank == 0:
             res["split_matches_single_gpu"] = res["trace_signature"] == res["single_gpu_trace_signature"]
         finish(0)

@@ -4,7 +4,13 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <math.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -175,8 +181,28 @@ struct crim_engine {
     void* d_peek = nullptr;         // scratch for crim_peek_fields
     // split search (one image, window-origin rows divided into parts)
     int split_parts = 0;            // 0: off
-    int split_rank = -1;            // >= 0: this process scores part `rank`, RCCL exchanges the bests
-    ncclComm_t comm = nullptr;
+    int split_rank = -1;            // >= 0: this process scores part `rank` and the ranks exchange their bests
+    ncclComm_t comm = nullptr;      // exchange by RCCL all-gather ...
+    struct HostExchange* hx = nullptr;   // ... or through host memory shared by the ranks' processes
+    std::vector<GraphSet> split_graphs;  // captured split iterations (64 / 8 / 1)
+    bool split_capture_failed = false;   // stream capture of the split iteration was refused: the loop runs eagerly
+    long split_exchanges = 0;            // records this process has exchanged through host memory
+};
+
+// Exchange of the ranks' shares of the search slots through a file-backed mapping shared by their
+// processes (ranks on one host; a transport for tests and for placements RCCL refuses, e.g. two processes
+// on ONE GPU).  Per rank and iteration parity one cell: a 64-byte header with the sequence number, then
+// the share.  A rank publishes iteration k in cell k % 2 and cannot reach k + 2 before every rank has
+// published k + 1, i.e. has read all cells of k: two cells per rank are enough.
+struct HostExchange {
+    int fd = -1;
+    unsigned char* map = nullptr;
+    size_t bytes = 0;
+    size_t share = 0, cell_bytes = 0;   // bytes of one rank's share of the slots; of one cell
+    int nranks = 0, rank = 0;
+    unsigned long long seq = 0;         // iterations exchanged so far
+    unsigned char* pinned = nullptr;    // page-locked staging: every rank's share, in rank order
+    unsigned char* cell(int r, unsigned long long k) { return map + ((size_t)r * 2 + (k & 1)) * cell_bytes; }
 };
 
 // RCCL is loaded on demand so that the library has no link-time dependency on it.
@@ -220,6 +246,18 @@ static void free_graphs(crim_engine* h) {
             if (g.exec) (void)hipGraphExecDestroy(g.exec);
         ln.graphs.clear();
     }
+    for (auto& g : h->split_graphs)
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    h->split_graphs.clear();
+}
+
+static void close_host_exchange(crim_engine* h) {
+    if (!h->hx) return;
+    if (h->hx->pinned) (void)hipHostFree(h->hx->pinned);
+    if (h->hx->map) munmap(h->hx->map, h->hx->bytes);
+    if (h->hx->fd >= 0) close(h->hx->fd);
+    delete h->hx;
+    h->hx = nullptr;
 }
 
 // Search over block rows [sy0, sy0 + rows) of the window-origin grid (all rows when rows < 0).
@@ -418,6 +456,7 @@ static void init_geometry(Params& p, int batch, int H, int W, int patch_size, un
     // the candidate grid is largest for the most clipped patch: (H - half) x (W - half)
     p.snx = (std::max(W - p.half, 1) + SB_W - 1) / SB_W;
     p.sny = (std::max(H - p.half, 1) + SB_H - 1) / SB_H;
+    p.srows = p.sny + 64;   // a split search exchanges equal shares of whole block rows: up to 64 shares
     p.generic = ((flags & CRIM_FLAG_GENERIC_SEARCH) || !has_fast_search(p.P)) ? 1 : 0;
     p.dot4 = (flags & CRIM_FLAG_DOT4_SEARCH) ? 1 : 0;
     // a candidate grid is at most W - half origins wide; the matrix-core kernels tile it 256 wide
@@ -500,13 +539,14 @@ extern "C" void crim_destroy(crim_t* h) {
         if (ln.stream) (void)hipStreamSynchronize(ln.stream);
     free_graphs(h);
     if (h->comm && g_rccl.comm_destroy) (void)g_rccl.comm_destroy(h->comm);
+    close_host_exchange(h);
     for (auto& ln : h->lanes)
         if (ln.stream) (void)hipStreamDestroy(ln.stream);
     for (auto e : h->ev)
         if (e) (void)hipEventDestroy(e);
     Params& p = h->prm;
     void* bufs[] = {p.bgr, p.planes, p.mask, p.grey, p.grad, p.conf, p.dterm, p.invalid, p.invbits, p.tfront, p.tlist, p.st,
-                    p.desc, p.plist, p.slist, p.xchg, p.trace, p.stime, p.dbg, h->d_gamma, h->d_cbrt, h->d_peek};
+                    p.desc, p.plist, p.slist, p.trace, p.stime, p.dbg, h->d_gamma, h->d_cbrt, h->d_peek};
     for (void* q : bufs)
         if (q) (void)hipFree(q);
     if (h->h_state) (void)hipHostFree(h->h_state);
@@ -557,9 +597,8 @@ extern "C" int crim_create_batch(int batch, int H, int W, int patch_size, int de
     alloc((void**)&p.st, Bz * sizeof(ImgState));
     alloc((void**)&p.desc, Bz * sizeof(Desc));
     alloc((void**)&p.plist, Bz * p.pgrid * sizeof(PEntry));
-    alloc((void**)&p.slist, Bz * p.snx * p.sny * sizeof(SEntry));
+    alloc((void**)&p.slist, Bz * p.snx * p.srows * sizeof(SEntry));
     alloc((void**)&p.dbg, kDbgSlots * sizeof(long long));
-    alloc((void**)&p.xchg, 64 * sizeof(SEntry));
     alloc((void**)&h->d_gamma, sizeof(t.gamma));
     alloc((void**)&h->d_cbrt, sizeof(t.cbrt_));
     if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_state, Bz * sizeof(ImgState), hipHostMallocDefault);
@@ -811,43 +850,164 @@ static int flush_profile(crim_engine* h) {
     return CRIM_OK;
 }
 
-// Fill loop with the search split into parts (one image).  Launched eagerly: every iteration is
-// priority, select, the search of this process's part(s) each folded into its exchange slot, the
-// RCCL all-gather of the 16-byte slots when the parts live in different processes, update.
+// The split of the search: block rows [y0, y1) of part `part` of `parts` -- equal shares of whole block
+// rows (the last ones may be short or empty), so that the parts' slots are equal, contiguous pieces of the
+// image's slot array and an all-gather can put them together in place.
+static int split_rows_per_part(const Params& p, int parts) { return (p.sny + parts - 1) / parts; }
+
+// One iteration of the fill loop with the search split into parts (one image): the search of this
+// process's part(s); when the parts live in different processes, the exchange of their slots (RCCL
+// all-gather on the stream, in place: afterwards every process holds every search block's best window,
+// exactly as after an unsplit search); the update, which reduces the slots as it always does.
+// Where the search launch can select the target itself it does (every part's launch picks the same
+// target), and the update shares its launch with the next iteration's priority stage (k_step), exactly
+// as in the unsplit loop; the sequence then starts with ONE priority launch issued by the caller.
+// `first_half` / `second_half`: a host-staged exchange sits between the two.
+static int launch_split_iteration(crim_engine* h, const Params& p, hipStream_t s, bool first_half, bool second_half) {
+    const int parts = h->split_parts;
+    const bool sel = search_selects(p);
+    const int rpp = split_rows_per_part(p, parts);
+    if (first_half) {
+        if (!p.fused) launch_priority(p, s);
+        if (!sel) hipLaunchKernelGGL(k_select, dim3(p.B), dim3(256), 0, s, p);
+        for (int part = 0; part < parts; ++part) {
+            if (h->split_rank >= 0 && part != h->split_rank) continue;
+            const int y0 = std::min(part * rpp, p.sny), y1 = std::min(y0 + rpp, p.sny);
+            launch_search(p, s, y0, y1 - y0, sel);
+        }
+        if (h->split_rank >= 0 && h->comm) {
+            const size_t share = (size_t)rpp * p.snx * sizeof(SEntry);
+            const ncclResult_t r = g_rccl.all_gather((const char*)p.slist + (size_t)h->split_rank * share, p.slist, share,
+                                                     ncclInt8, h->comm, s);
+            if (r != ncclSuccess)
+                return fail(CRIM_ERR_HIP, "ncclAllGather: %s", g_rccl.error_string ? g_rccl.error_string(r) : "error");
+        }
+    }
+    if (second_half) {
+        if (p.fused) launch_step(p, s);
+        else launch_update(p, s);
+    }
+    return CRIM_OK;
+}
+
+// Publishes this rank's share of the current iteration's slots and collects every other rank's (host
+// memory shared by the ranks' processes).  Gives up after 60 s without progress: a peer that died must
+// not hang the others.
+static int host_exchange(crim_engine* h, const Params& p, hipStream_t s) {
+    HostExchange& x = *h->hx;
+    unsigned char* d_slots = (unsigned char*)p.slist;
+    HIP_TRY(hipMemcpyAsync(x.pinned + (size_t)x.rank * x.share, d_slots + (size_t)x.rank * x.share, x.share,
+                           hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const unsigned long long k = ++x.seq;
+    unsigned char* mine = x.cell(x.rank, k);
+    memcpy(mine + 64, x.pinned + (size_t)x.rank * x.share, x.share);
+    __atomic_store_n((unsigned long long*)mine, k, __ATOMIC_RELEASE);
+    struct timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int r = 0; r < x.nranks; ++r) {
+        if (r == x.rank) continue;
+        unsigned char* c = x.cell(r, k);
+        for (unsigned spins = 0; __atomic_load_n((unsigned long long*)c, __ATOMIC_ACQUIRE) != k; ++spins) {
+            if ((spins & 1023) == 1023) {
+                sched_yield();
+                struct timespec t1;
+                clock_gettime(CLOCK_MONOTONIC, &t1);
+                if (t1.tv_sec - t0.tv_sec > 60)
+                    return fail(CRIM_ERR_STATE, "split search: rank %d did not publish iteration %llu within 60 s", r, k);
+            }
+        }
+        memcpy(x.pinned + (size_t)r * x.share, c + 64, x.share);
+        HIP_TRY(hipMemcpyAsync(d_slots + (size_t)r * x.share, x.pinned + (size_t)r * x.share, x.share,
+                               hipMemcpyHostToDevice, s));
+    }
+    h->split_exchanges += 1;
+    return CRIM_OK;
+}
+
+// Captures `iters` split iterations (no host-staged exchange) into a graph.  RCCL calls are capturable;
+// should the runtime refuse, the caller falls back to eager launches and remembers why.
+static int build_split_graph(crim_engine* h, const Params& p, hipStream_t s, int iters, GraphSet* out) {
+    hipGraph_t graph = nullptr;
+    HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    int rc = CRIM_OK;
+    const int period = compact_period(p);
+    for (int i = 0; i < iters && rc == CRIM_OK; ++i) {
+        rc = launch_split_iteration(h, p, s, true, true);
+        if ((i + 1) % period == 0) launch_compact(p, s);
+    }
+    const hipError_t ce = hipStreamEndCapture(s, &graph);
+    if (rc != CRIM_OK || ce != hipSuccess || !graph) {
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        if (rc == CRIM_OK) fail(CRIM_ERR_HIP, "stream capture of the split iteration: %s", hipGetErrorString(ce));
+        return CRIM_ERR_HIP;
+    }
+    hipGraphExec_t exec = nullptr;
+    const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) return fail(CRIM_ERR_HIP, "hipGraphInstantiate (split iteration): %s", hipGetErrorString(e));
+    out->exec = exec;
+    out->iters = iters;
+    return CRIM_OK;
+}
+
+// Fill loop with the search split into parts (one image).
 static int run_split(crim_engine* h, long max_iters) {
     Lane& ln = h->lanes[0];
     Params p = ln.prm;
-    p.nparts = h->split_parts;
-    const int parts = h->split_parts;
-    long done = 0;
+    const bool eager_flag = (h->flags & CRIM_FLAG_EAGER) != 0;
+    const bool want_graphs = !eager_flag && !h->hx && !h->split_capture_failed && !getenv("CRIM_SPLIT_EAGER");
+    if (want_graphs && h->split_graphs.empty()) {
+        static const int sizes[3] = {64, 8, 1};
+        for (int sz : sizes) {
+            GraphSet g;
+            if (build_split_graph(h, p, ln.stream, sz, &g) != CRIM_OK) {
+                h->split_capture_failed = true;   // crim_last_error() keeps the reason
+                for (auto& q : h->split_graphs)
+                    if (q.exec) (void)hipGraphExecDestroy(q.exec);
+                h->split_graphs.clear();
+                break;
+            }
+            h->split_graphs.push_back(g);
+        }
+    }
+    const bool graphs = want_graphs && !h->split_graphs.empty();
+    long done = 0, last = 0;
+    int prev_remaining = -1;
     for (;;) {
         HIP_TRY(hipMemcpyAsync(h->h_state, p.st, sizeof(ImgState), hipMemcpyDeviceToHost, ln.stream));
         HIP_TRY(hipStreamSynchronize(ln.stream));
-        const ImgState& s = h->h_state[0];
-        if (s.stalled || !s.live) break;
-        long need = std::max(1L, ((long)s.remaining + p.P * p.P - 1) / (p.P * p.P));
-        need = std::min(need, 64L);
+        const ImgState& st = h->h_state[0];
+        if (st.stalled || !st.live) break;
+        long need = std::max(1L, ((long)st.remaining + p.P * p.P - 1) / (p.P * p.P));
+        // (every rank sees the same state, so every rank extrapolates to the same number of iterations)
+        const int filled = prev_remaining - st.remaining;
+        if (last > 0 && prev_remaining >= 0 && filled > 0)
+            need = std::max(need, (long)((double)st.remaining * (double)last / (double)filled));
+        prev_remaining = st.remaining;
+        if (!graphs) need = std::min(need, 256L);
         if (max_iters > 0) need = std::min(need, max_iters - done);
         if (need <= 0) break;
-        for (long it = 0; it < need; ++it) {
-            if ((done + it) > 0 && (done + it) % compact_period(p) == 0) launch_compact(p, ln.stream);
-            launch_priority(p, ln.stream);
-            hipLaunchKernelGGL(k_select, dim3(p.B), dim3(256), 0, ln.stream, p);
-            for (int part = 0; part < parts; ++part) {
-                if (h->split_rank >= 0 && part != h->split_rank) continue;
-                const int y0 = (int)((long)p.sny * part / parts), y1 = (int)((long)p.sny * (part + 1) / parts);
-                launch_search(p, ln.stream, y0, y1 - y0);
-                hipLaunchKernelGGL(k_local_best, dim3(1), dim3(256), 0, ln.stream, p, part, y0, y1 - y0);
+        if (p.fused) launch_priority(p, ln.stream);   // the sequence's first priority stage (idempotent)
+        if (graphs) {
+            long left = need;
+            for (auto& g : h->split_graphs)
+                while (left >= g.iters) {
+                    HIP_TRY(hipGraphLaunch(g.exec, ln.stream));
+                    left -= g.iters;
+                }
+        } else {
+            for (long it = 0; it < need; ++it) {
+                if ((done + it) > 0 && (done + it) % compact_period(p) == 0) launch_compact(p, ln.stream);
+                int rc = launch_split_iteration(h, p, ln.stream, true, false);
+                if (rc == CRIM_OK && h->hx) rc = host_exchange(h, p, ln.stream);
+                if (rc == CRIM_OK) rc = launch_split_iteration(h, p, ln.stream, false, true);
+                if (rc) return rc;
             }
-            if (h->split_rank >= 0) {
-                const ncclResult_t r = g_rccl.all_gather(p.xchg + h->split_rank, p.xchg, sizeof(SEntry),
-                                                         ncclInt8, h->comm, ln.stream);
-                if (r != ncclSuccess)
-                    return fail(CRIM_ERR_HIP, "ncclAllGather: %s", g_rccl.error_string ? g_rccl.error_string(r) : "error");
-            }
-            launch_update(p, ln.stream);
         }
         done += need;
+        last = need;
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipMemcpyAsync(h->h_state, p.st, sizeof(ImgState), hipMemcpyDeviceToHost, ln.stream));
@@ -883,8 +1043,62 @@ extern "C" int crim_split_init(crim_t* h, int nranks, int rank, const void* uniq
     const ncclResult_t r = g_rccl.comm_init_rank(&h->comm, nranks, id, rank);
     if (r != ncclSuccess)
         return fail(CRIM_ERR_HIP, "ncclCommInitRank: %s", g_rccl.error_string ? g_rccl.error_string(r) : "error");
+    close_host_exchange(h);
+    free_graphs(h);
+    h->prepared = false;
+    h->split_capture_failed = false;
     h->split_parts = nranks;
     h->split_rank = rank;
+    return CRIM_OK;
+}
+
+extern "C" int crim_split_init_host(crim_t* h, int nranks, int rank, const char* shared_file) {
+    if (!h || !shared_file) return fail(CRIM_ERR_ARG, "crim_split_init_host: null argument");
+    if (h->prm.B != 1) return fail(CRIM_ERR_ARG, "crim_split_init_host: the split search handles one image per engine");
+    if (nranks < 1 || nranks > 63 || rank < 0 || rank >= nranks)
+        return fail(CRIM_ERR_ARG, "crim_split_init_host: rank %d of %d", rank, nranks);
+    HIP_TRY(hipSetDevice(h->device));
+    if (h->comm && g_rccl.comm_destroy) { (void)g_rccl.comm_destroy(h->comm); h->comm = nullptr; }
+    close_host_exchange(h);
+    HostExchange* x = new (std::nothrow) HostExchange();
+    if (!x) return fail(CRIM_ERR_NOMEM, "crim_split_init_host: out of host memory");
+    h->hx = x;
+    x->nranks = nranks;
+    x->rank = rank;
+    x->share = (size_t)split_rows_per_part(h->prm, nranks) * h->prm.snx * sizeof(SEntry);
+    x->cell_bytes = 64 + ((x->share + 63) & ~(size_t)63);
+    x->bytes = (size_t)nranks * 2 * x->cell_bytes;
+    x->fd = open(shared_file, O_RDWR | O_CREAT, 0600);
+    if (x->fd < 0 || ftruncate(x->fd, (off_t)x->bytes) != 0) {
+        close_host_exchange(h);
+        return fail(CRIM_ERR_STATE, "crim_split_init_host: cannot open or size %s", shared_file);
+    }
+    void* m = mmap(nullptr, x->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, x->fd, 0);
+    if (m == MAP_FAILED) {
+        close_host_exchange(h);
+        return fail(CRIM_ERR_STATE, "crim_split_init_host: cannot map %s", shared_file);
+    }
+    x->map = (unsigned char*)m;
+    if (hipHostMalloc((void**)&x->pinned, (size_t)nranks * x->share, hipHostMallocDefault) != hipSuccess) {
+        x->pinned = nullptr;
+        close_host_exchange(h);
+        return fail(CRIM_ERR_NOMEM, "crim_split_init_host: page-locked staging");
+    }
+    free_graphs(h);
+    h->prepared = false;
+    h->split_parts = nranks;
+    h->split_rank = rank;
+    h->split_exchanges = 0;
+    return CRIM_OK;
+}
+
+// How the split loop ran: *graph_captured = 1 when its iterations are replayed from captured graphs (0:
+// eager launches, because a host-staged exchange sits inside every iteration, the engine is eager, or
+// the runtime refused the capture), *host_exchanges = records exchanged through host memory so far.
+extern "C" int crim_split_status(crim_t* h, int* graph_captured, long* host_exchanges) {
+    if (!h) return fail(CRIM_ERR_ARG, "crim_split_status: null handle");
+    if (graph_captured) *graph_captured = h->split_graphs.empty() ? 0 : 1;
+    if (host_exchanges) *host_exchanges = h->split_exchanges;
     return CRIM_OK;
 }
 
@@ -903,6 +1117,11 @@ extern "C" int crim_split_virtual(crim_t* h, int nparts) {
     if (!h) return fail(CRIM_ERR_ARG, "crim_split_virtual: null handle");
     if (h->prm.B != 1) return fail(CRIM_ERR_ARG, "crim_split_virtual: the split search handles one image per engine");
     if (nparts < 0 || nparts > 64) return fail(CRIM_ERR_ARG, "crim_split_virtual: %d parts", nparts);
+    close_host_exchange(h);
+    if (h->split_parts != nparts || h->split_rank != -1) {
+        free_graphs(h);
+        h->prepared = false;
+    }
     h->split_parts = nparts;
     h->split_rank = -1;
     return CRIM_OK;
@@ -1304,9 +1523,8 @@ static void noalloc_layout(NoallocLayout& L, int H, int W, int patch_size, unsig
     c.take(&p.st, sizeof(ImgState));
     c.take(&p.desc, sizeof(Desc));
     c.take(&p.plist, (size_t)p.pgrid * sizeof(PEntry));
-    c.take(&p.slist, (size_t)p.snx * p.sny * sizeof(SEntry));
+    c.take(&p.slist, (size_t)p.snx * p.srows * sizeof(SEntry));
     c.take(&p.dbg, kDbgSlots * sizeof(long long));
-    c.take(&p.xchg, 64 * sizeof(SEntry));
     c.take(&L.d_gamma, sizeof(t.gamma));
     c.take(&L.d_cbrt, sizeof(t.cbrt_));
     L.used = c.used;

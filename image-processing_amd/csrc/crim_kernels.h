@@ -1297,7 +1297,7 @@ __device__ __forceinline__ double cand_cost(const Desc* d, int S, int y, int x) 
 __device__ __forceinline__ void emit_empty(const Params& p, int b, int slot) {
     SEntry e;
     e.cost = INFINITY; e.idx = 0xffffffffu; e.pad = 0;
-    p.slist[(size_t)b * p.snx * p.sny + slot] = e;
+    p.slist[(size_t)b * p.snx * p.srows + slot] = e;
 }
 
 __device__ __forceinline__ void block_min_emit(const Params& p, int b, int slot, double bc, unsigned bi,
@@ -1315,7 +1315,7 @@ __device__ __forceinline__ void block_min_emit(const Params& p, int b, int slot,
             if (better_cost(s_c[w], s_i[w], bc, bi)) { bc = s_c[w]; bi = s_i[w]; }
         SEntry e;
         e.cost = bc; e.idx = bi; e.pad = 0;
-        p.slist[(size_t)b * p.snx * p.sny + slot] = e;
+        p.slist[(size_t)b * p.snx * p.srows + slot] = e;
     }
 }
 
@@ -1843,7 +1843,7 @@ void k_search_mfma(Params p) {
             if (better_cost(s_c[w], s_i[w], bc, bi)) { bc = s_c[w]; bi = s_i[w]; }
         SEntry e;
         e.cost = bc; e.idx = bi; e.pad = 0;
-        p.slist[(size_t)b * p.snx * p.sny + slot] = e;
+        p.slist[(size_t)b * p.snx * p.srows + slot] = e;
     }
     STAMP_MID(40);
 }
@@ -2229,7 +2229,7 @@ void k_search_pipe(Params p) {
             if (better_cost(s_c[w], s_i[w], bc, bi)) { bc = s_c[w]; bi = s_i[w]; }
         SEntry e;
         e.cost = bc; e.idx = bi; e.pad = 0;
-        p.slist[(size_t)b * p.snx * p.sny + tb * p.snx + tbx] = e;
+        p.slist[(size_t)b * p.snx * p.srows + tb * p.snx + tbx] = e;
     };
 
     // ring slot of stream load NP * t + i: (tbase + i) % 3 with tbase = (NP * t) % 3
@@ -2477,44 +2477,6 @@ __global__ __launch_bounds__(256) void k_search_generic(Params p) {
     block_min_emit(p, b, (p.sy0 + (int)blockIdx.y) * p.snx + (int)blockIdx.x, bc, bi, s_c, s_i);
 }
 
-// Split search (one image, the window-origin rows divided into parts that different launches --
-// on one GPU or on several -- score): folds the partial list of the part just searched into
-// slot `part` of the exchange array and empties the list for the next part.  Every process then
-// holds all slots (directly, or after an all-gather) and k_update reduces them.
-__global__ __launch_bounds__(256) void k_local_best(Params p, int part, int row0, int nrows) {
-    const int b = p.b0;
-    ImgState* st = p.st + b;
-    if (!st->live) return;
-    __shared__ double s_c[4];
-    __shared__ unsigned s_i[4];
-    const int tid = threadIdx.x;
-    const Desc* d = p.desc + b;
-    const SEntry* sl = p.slist + (size_t)b * p.snx * p.sny;
-    const int grows = (d->ncy + SB_H - 1) / SB_H, gcols = search_cols(p, d->ncx);
-    const int row1 = row0 + nrows < grows ? row0 + nrows : grows;
-    double bc = INFINITY;
-    unsigned bi = 0xffffffffu;
-    for (int i = row0 * p.snx + tid; i < row1 * p.snx; i += 256) {
-        if (!slot_in_grid(p, i, row0, row1, gcols)) continue;
-        const SEntry e = sl[i];
-        if (better_cost(e.cost, e.idx, bc, bi)) { bc = e.cost; bi = e.idx; }
-    }
-    {
-        int bi_ = (int)bi;
-        wave_best_pair(bc, bi_, [](double ca, int ia, double cb, int ib) { return better_cost(ca, (unsigned)ia, cb, (unsigned)ib); });
-        bi = (unsigned)bi_;
-    }
-    if ((tid & 63) == 0) { s_c[tid >> 6] = bc; s_i[tid >> 6] = bi; }
-    __syncthreads();
-    if (tid == 0) {
-        for (int w = 1; w < 4; ++w)
-            if (better_cost(s_c[w], s_i[w], bc, bi)) { bc = s_c[w]; bi = s_i[w]; }
-        SEntry e;
-        e.cost = bc; e.idx = bi; e.pad = 0;
-        p.xchg[part] = e;
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // iteration kernel 4: pick the source, copy the patch, maintain every cached field
 // ------------------------------------------------------------------------------------------
@@ -2554,11 +2516,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PM <= 9 ? 8
     // capacity; entries beyond the count are ignored once the count has arrived).
     // The slots are visited in a compact order that skips the block columns the active tiling never
     // uses: compact index c is block row c / scols, block column c % scols.
-    const SEntry* sl = p.nparts > 0 ? p.xchg : p.slist + (size_t)b * p.snx * p.sny;
-    const int scols = p.nparts > 0 ? p.nparts : p.scols;
-    const int srows = p.nparts > 0 ? 1 : p.sny;
-    const int sstride = p.nparts > 0 ? p.nparts : p.snx;
-    auto slot_of = [&](int c) { const int r = c / scols; return imin(r, srows - 1) * sstride + (c - r * scols); };
+    const SEntry* sl = p.slist + (size_t)b * p.snx * p.srows;
+    const int scols = p.scols;
+    auto slot_of = [&](int c) { const int r = c / scols; return imin(r, p.sny - 1) * p.snx + (c - r * scols); };
     constexpr int NSPEC = 4;
     SEntry spec[NSPEC];
 #pragma unroll
@@ -2570,10 +2530,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PM <= 9 ? 8
     const unsigned tcount0 = st->tcount;
     const int tlsel = st->tlsel;
     const int ncx = d->ncx;
-    // entries to reduce: the exchange slots of a split search, else the slots of the search blocks
-    // inside the candidate grid
-    const int grows = p.nparts > 0 ? 1 : (d->ncy + SB_H - 1) / SB_H;
-    const int gcols = p.nparts > 0 ? p.nparts : search_cols(p, ncx);
+    // entries to reduce: the slots of the search blocks inside the candidate grid (a split search fills
+    // them part by part, in this process or -- exchanged before this launch -- in others)
+    const int grows = (d->ncy + SB_H - 1) / SB_H;
+    const int gcols = search_cols(p, ncx);
     const int n = grows * scols;   // compact indices that can name a slot inside the candidate grid
     const int r0 = d->r0, c0 = d->c0, ph = d->ph, pw = d->pw;
     const double cnew = d->cnew;

@@ -306,11 +306,9 @@ __device__ __forceinline__ void step_near(const Params& p, const int b, const De
 
     STAMP_AT(1, 40);
     // Load batch 1: the search's per-block results (as k_update reads them) and the descriptor.
-    const SEntry* sl = p.nparts > 0 ? p.xchg : p.slist + (size_t)b * p.snx * p.sny;
-    const int scols = p.nparts > 0 ? p.nparts : p.scols;
-    const int srows = p.nparts > 0 ? 1 : p.sny;
-    const int sstride = p.nparts > 0 ? p.nparts : p.snx;
-    auto slot_of = [&](int c) { const int r = c / scols; return imin(r, srows - 1) * sstride + (c - r * scols); };
+    const SEntry* sl = p.slist + (size_t)b * p.snx * p.srows;
+    const int scols = p.scols;
+    auto slot_of = [&](int c) { const int r = c / scols; return imin(r, p.sny - 1) * p.snx + (c - r * scols); };
     constexpr int NSPEC = 4;
     SEntry spec[NSPEC];
 #pragma unroll
@@ -319,8 +317,8 @@ __device__ __forceinline__ void step_near(const Params& p, const int b, const De
     if (tid < PT * PT) kf = d->kflat[tid];
     const int live = d->live;   // written by this iteration's search launch
     const int ncx = d->ncx;
-    const int grows = p.nparts > 0 ? 1 : (d->ncy + SB_H - 1) / SB_H;
-    const int gcols = p.nparts > 0 ? p.nparts : search_cols(p, ncx);
+    const int grows = (d->ncy + SB_H - 1) / SB_H;
+    const int gcols = search_cols(p, ncx);
     const int n = grows * scols;
     const int r0 = d->r0, c0 = d->c0, ph = d->ph, pw = d->pw;
     const int cur = d->cur;

@@ -104,13 +104,13 @@ struct Params {
     int Wb;       // 64-bit words per row of the window-validity bitmap
     int tnx, tny; // 16x16 tile grid over the whole image (upload-time kernels)
     int snx, sny; // search block grid
+    int srows;    // rows of the per-image slot array (sny rounded up so that equal shares of a split search fit)
     int sy0;      // first block row a search launch covers (split search; 0 otherwise)
     int dmax;     // upper bound of the distance term of the search cost: ceil(sqrt(H^2 + W^2)) + 1
     int mgx, mrows; // matrix-core search launch: blocks per row of tiles, rows of tiles covered
     int mtiles, mchunks; // pipelined matrix-core search: rows of tiles per block, blocks per column of tiles
     int pipe_force;   // host side: > 0 fixes the rows of tiles per block (experiments)
     int pipe_t, pipe_min_blocks; // host side: most rows of tiles per block (0 = plain kernel), launch size below which fewer are used
-    int nparts;   // > 0: split search, k_update reduces xchg[0..nparts) instead of the partial list
     int pgrid;    // priority slots per image: one per wave of the priority stage
     int fused;    // host side: an iteration is the search launch (which also selects) and ONE launch that
                   // updates the image and evaluates the next iteration's priorities (k_step)
@@ -137,8 +137,7 @@ struct Params {
     int* tlist;        // [B][2][tcap] tiles the priority stage visits (two buffers: a rebuild that runs beside
                        // readers of the list writes the other one, ImgState::tlsel names the current one)
     PEntry* plist;     // [B][pgrid]
-    SEntry* slist;     // [B][snx*sny]
-    SEntry* xchg;      // [64] per-part best window of a split search
+    SEntry* slist;     // [B][snx*srows] one slot per search block (row-major block rows)
     crim_iter_rec* trace;  // [B][trace_cap]
     float* stime;          // [B][trace_cap] microseconds from the end of the selection to the start of the update
     long long* dbg;        // diagnostic stamps (only written by -DCRIM_STAMPS builds)

@@ -106,14 +106,17 @@ int crim_host_free(void* ptr);
  * the largest per-image iteration count so far, remaining the total masked pixels left. */
 int crim_run(crim_t* h, long max_iters, long* iters_done, long* remaining);
 
-/* Split search for ONE large image (batch 1): the rows of window origins scored by
- * _find_source_patch (:240-264) are divided into parts; each part's best window is a 16-byte
- * (cost, index) record and the lexicographic minimum over the parts is the reference's arg-min.
- * No counterpart in the reference (it is single-process).
+/* Split search for ONE large image (batch 1): the block rows of window origins scored by
+ * _find_source_patch (:240-264) are divided into equal parts; a search block's best window is a
+ * 16-byte (cost, index) slot, the parts' slots are contiguous pieces of one array, and the
+ * lexicographic minimum over all slots is the reference's arg-min.  No counterpart in the reference (it
+ * is single-process).
  *   crim_split_virtual: the parts are scored one after another by this engine (checks the
  *     partitioning on one GPU; nparts 0 switches the split off).
  *   crim_split_init: this process scores part `rank` of `nranks`; every process holds a replica
- *     of the image state and the records are exchanged by one RCCL all-gather per iteration.
+ *     of the image state and the parts' slots are put together by one in-place RCCL all-gather per
+ *     iteration (a few KB per rank; captured, with the iteration's kernels, into the hipGraphs the loop
+ *     replays), after which every process reduces all slots exactly as after an unsplit search.
  *     unique_id128 is the 128-byte id rank 0 obtained from crim_split_unique_id and shared out of
  *     band (e.g. torch.distributed broadcast). */
 int crim_split_virtual(crim_t* h, int nparts);
@@ -121,6 +124,17 @@ int crim_split_unique_id(void* out128);
 int crim_split_init(crim_t* h, int nranks, int rank, const void* unique_id128);
 /* Size and rank of the RCCL communicator as RCCL itself reports them (after crim_split_init). */
 int crim_split_info(crim_t* h, int* nranks, int* rank);
+/* The same split with the slots exchanged through host memory instead of RCCL: every rank's process
+ * (all on one host) maps `shared_file` (a fresh path, the same for all ranks), publishes its share there
+ * each iteration and reads the others' (device -> host, shared mapping, host -> device).  For
+ * tests and for placements RCCL refuses, e.g. two ranks on ONE GPU; the host is in the loop every
+ * iteration, so it is slow. */
+int crim_split_init_host(crim_t* h, int nranks, int rank, const char* shared_file);
+/* How the split loop runs: *graph_captured = 1 when its iterations (RCCL all-gather included) are
+ * replayed from captured hipGraphs, 0 when they are launched one by one (host-staged exchange, eager
+ * engine, or a runtime that refused the capture: crim_last_error() then holds the reason);
+ * *host_exchanges = iterations exchanged through host memory so far.  Null outputs are skipped. */
+int crim_split_status(crim_t* h, int* graph_captured, long* host_exchanges);
 
 /* working_image (:88), confidence and working_mask after the run; null outputs are skipped. */
 int crim_download(crim_t* h, uint8_t* bgr_out, double* conf_out, uint8_t* mask_out);

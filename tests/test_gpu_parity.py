@@ -868,6 +868,25 @@ def test_split_search_virtual_parts(nparts):
         eng.run()
         out, conf, _ = eng.download(want_conf=True)
         tr = eng.trace(0)
+        captured, _ = eng.split_status()
+    assert np.array_equal(tr, otr.astype(capi.ITER_REC_DTYPE))
+    assert np.array_equal(out[0], oout) and np.array_equal(conf[0], oconf)
+    assert captured, "the split iterations were not replayed from captured graphs"
+
+
+@pytest.mark.parametrize("p,eager", [(9, True), (6, False), (15, False)])
+def test_split_search_other_loops(p, eager):
+    """The split loop launched eagerly, with a patch size that has no select-in-search instance (priority,
+    select and update as launches of their own), and at patch edge 15."""
+    img = crim_synth.xray_like(120, 136, 1300 + p, colour=True)
+    m = crim_synth.blob_mask(120, 136, 1300 + p, fraction=0.07, margin=9)
+    oout, oconf, _, otr, n = c_oracle.run(img, m, p)
+    with capi.Engine(120, 136, p, flags=capi.FLAG_EAGER if eager else 0) as eng:
+        eng.split_virtual(3)
+        eng.upload(img, m)
+        eng.run()
+        out, conf, _ = eng.download(want_conf=True)
+        tr = eng.trace(0)
     assert np.array_equal(tr, otr.astype(capi.ITER_REC_DTYPE))
     assert np.array_equal(out[0], oout) and np.array_equal(conf[0], oconf)
 
@@ -889,9 +908,10 @@ with capi.Engine(96, 96, 9) as eng:
     eng.run()
     out, conf, _ = eng.download(want_conf=True)
     tr = eng.trace(0)
+    eng_status = eng.split_status()[0]
 assert np.array_equal(tr, otr.astype(capi.ITER_REC_DTYPE))
 assert np.array_equal(out[0], oout) and np.array_equal(conf[0], oconf)
-print("RCCL_SINGLE_RANK_OK", n)
+print("RCCL_SINGLE_RANK_OK", n, "graph captured:", eng_status)
 """
 
 
@@ -906,3 +926,42 @@ def test_split_search_rccl_single_rank():
     r = subprocess.run([sys.executable, "-c", _RCCL_SCRIPT % (ROOT, PKG)], capture_output=True,
                        text=True, timeout=240)
     assert r.returncode == 0 and "RCCL_SINGLE_RANK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_split_search_two_processes_on_one_gpu(tmp_path):
+    """The split search with MORE than one rank: two worker processes, each with its own replica of a
+    1024x1024 image on this one GPU, each scoring only its half of the window-origin rows and consuming the
+    other's record every iteration (records exchanged through host memory: RCCL refuses two ranks on one
+    device).  Both ranks' per-iteration records must equal the unsplit engine's over 232 iterations, and
+    the oracle's over the first ones."""
+    import crim_split_worker as sw
+    rdv = str(tmp_path / "rdv")
+    S, iters = 1024, 200
+    procs = [sw.launch_worker(r, 2, 0, rdv, size=S, patch=9, iters=iters, transport="host", dump_trace=True, wait=120)
+             for r in range(2)]
+    try:
+        sw.release(rdv)
+        res = sw.collect(rdv, 2, 240.0)
+        for pr in procs:
+            pr.wait(timeout=60)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    logs = "".join(open(os.path.join(rdv, "worker.%d.log" % r)).read()[-1500:] for r in range(2))
+    assert all(r is not None and not r.get("error") for r in res), (res, logs)
+    for r in res:
+        assert r["transport"] == "host" and r["host_exchanges"] == iters + 32 and not r["graph_captured"]
+    assert res[0]["split_matches_single_gpu"]
+    traces = [np.load(os.path.join(rdv, "trace.%d.npy" % r)) for r in range(2)]
+    img = crim_synth.xray_like(S, S, 4000 + S, colour=True)
+    mask = crim_synth.square_hole_mask(S, S, S // 2)
+    with capi.Engine(S, S, 9) as eng:
+        eng.upload(img, mask)
+        eng.run(max_iters=iters + 32)
+        want = eng.trace(0)
+    assert len(want) == iters + 32
+    for r in range(2):
+        assert np.array_equal(traces[r], want), "rank %d" % r
+    otr = c_oracle.run(img, mask, 9, max_iters=4)[3]
+    assert np.array_equal(want[:4], otr.astype(capi.ITER_REC_DTYPE))
