@@ -105,6 +105,55 @@ def pmc_traffic_per_launch(images_per_launch):
         return None
 
 
+def stencil_roofline():
+    """The stencil stages (front / confidence / data / priority: k_priority; update: k_update) of the
+    headline batch against the HBM roof: (FETCH_SIZE + WRITE_SIZE) per launch from the committed rocprofv3
+    PMC passes over the average launch duration of the kernel trace of the same command
+    (profiles/pmc_stencil_latest.json, written by tools/pmc_passes.sh; counters cannot be read from inside
+    the benchmark).  None when no summary is present."""
+    path = os.path.join(ROOT, "profiles", "pmc_stencil_latest.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None
+    out = {"source": "profiles/pmc_stencil_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, "
+                     "--kernel-trace --stats for the durations; FETCH_SIZE as counted, in KB of 1024 B)",
+           "peak": HBM_PEAK_GBS, "unit": "GB/s", "bound": "hbm"}
+    for k, v in d.get("kernels", {}).items():
+        try:
+            byts = (v["FETCH_SIZE_KB_per_launch"] + v["WRITE_SIZE_KB_per_launch"]) * 1024.0
+            gbs = byts / (v["avg_launch_us"] * 1e-6) / 1e9
+            out[k] = {"traffic": byts, "avg_launch_us": v["avg_launch_us"], "achieved": gbs, "frac": gbs / HBM_PEAK_GBS,
+                      "share_of_gpu_time": v.get("share_of_gpu_time"), "images_per_launch": v.get("images_per_launch"),
+                      "salu_per_valu": v.get("salu_per_valu")}
+        except (KeyError, ZeroDivisionError):
+            continue
+    return out
+
+
+def launch_split(capi, h, w, patch, upload, device, iters):
+    """Where an iteration's microseconds go, from three device time stamps per iteration (start of the launch
+    that selects and searches, end of the selection, start of the launch that follows the search): a
+    traced run of `iters` iterations on an engine of its own."""
+    with capi.Engine(h, w, patch, device=device) as e:
+        upload(e)
+        e.run(max_iters=64)
+        e.run(max_iters=iters)
+        st = e.iteration_stamps(0)[64:].astype(np.float64) * 0.01          # microseconds
+    if len(st) < 8:
+        return None
+    search = st[:, 2] - st[:, 0]                       # selecting launch start -> following launch start
+    rest = st[1:, 0] - st[:-1, 2]                      # following launch start -> next selecting launch start
+    ok = rest < 10 * np.median(rest)                   # (graph boundaries and host rounds excluded)
+    return {"search_launch_us": float(np.median(search)), "of_which_selection_us": float(np.median(st[:, 1] - st[:, 0])),
+            "update_and_next_priority_launch_us": float(np.median(rest[ok])),
+            "iteration_us_by_stamps": float(np.median((st[1:, 0] - st[:-1, 0])[ok])),
+            "note": "medians over %d iterations; each figure runs from the start of one launch to the start of the "
+                    "next, so launch boundaries are included; an iteration is two launches: the search (which "
+                    "also selects the target) and k_step (update + the next iteration's priority stage)" % len(st)}
+
+
 def _cpu_one(args):
     from oracle import c_oracle
     img, mask = args
@@ -134,6 +183,66 @@ def cpu_baseline(imgs, masks, budget_images_per_core=4):
                       "oracle/criminisi_oracle.c, one image per process, %d processes = every core this "
                       "job may use (affinity mask and OMP_NUM_THREADS; os.cpu_count() shows %s for the "
                       "whole machine); %.1f s wall, %d iterations" % (n, cores, os.cpu_count(), wall, iters)}
+
+
+def _cpu_crc(args):
+    from oracle import c_oracle
+    import zlib
+    img, mask = args
+    return zlib.crc32(c_oracle.run(img, mask, PATCH, want_trace=False)[0].tobytes())
+
+
+def cpu_outputs_crc(imgs, masks, count):
+    """CRC-32 of the C oracle's output for the first `count` images (one process each)."""
+    import multiprocessing as mp
+    from oracle import c_oracle
+    c_oracle._lib()
+    with mp.get_context("fork").Pool(min(host_cores(), count)) as pool:
+        return pool.map(_cpu_crc, [(imgs[i], masks[i]) for i in range(count)])
+
+
+def single_image(capi, device, img, mask):
+    """configs[1] as BASELINE words it: ONE 256x256 image, start to finish (upload, fill, download)."""
+    with capi.Engine(H, W, PATCH, device=device, flags=capi.FLAG_NO_TRACE) as eng:
+        eng.upload(img, mask)
+        eng.run()                              # builds the graphs
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            eng.upload(img, mask)
+            it, rem = eng.run()
+            out = eng.download()[0][0]
+            ts.append(time.perf_counter() - t0)
+        t_fill = []
+        for _ in range(5):
+            eng.upload(img, mask)
+            t0 = time.perf_counter()
+            it, rem = eng.run()
+            t_fill.append(time.perf_counter() - t0)
+    dt, df = float(np.median(ts)), float(np.median(t_fill))
+    return {"what": "one 256x256 grey image of the batch alone on the GPU (batch of 1), host arrays in and out; "
+                    "median of 5", "seconds": dt, "images_per_s": 1.0 / dt, "iterations": int(it),
+            "fill_loop_seconds": df, "us_per_iteration": 1e6 * df / max(int(it), 1),
+            "launches_us": launch_split(capi, H, W, PATCH, lambda e: e.upload(img, mask), device, 200)}, out
+
+
+def directory_driver_runs():
+    """JPEG in -> JPEG out through the directory driver (the loop of scripts/main.py:41-60), in processes of
+    their own: the driver forks its JPEG workers before it touches the GPU."""
+    import subprocess
+    out = {}
+    for key, extra in (("dataset_100_images", ["--dataset"]), ("synthetic_2048_images", ["--images", "2048", "--batch", "512"])):
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_directory.py")] + extra,
+                               capture_output=True, text=True, timeout=240)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            out[key] = json.loads(line[-1]) if line else {"error": (r.stderr or r.stdout)[-400:]}
+        except Exception as e:                              # noqa: BLE001 (a side measurement must not end the run)
+            out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+    out["note"] = ("crim_batch_driver.inpaint_directory: list *.jpg, decode (Pillow, worker processes), mask on the "
+                   "GPU, fill in lock-step batches, encode and write under the same names; seconds cover the whole "
+                   "call incl. engine creation and graph capture; dataset_100_images is the reference's own set")
+    return out
 
 
 def cpu_seconds_per_iteration(img, mask, patch, iters=2):
@@ -186,10 +295,12 @@ def search_roofline(capi, h, w, patch, batch, upload, kernel, planes, hbm_reside
 def config_dataset(capi, device, steps):
     """configs[0]: the reference's 100 dataset images (scripts/main.py loop), patch 9, one lock-step
     batch; host arrays in, host arrays out."""
-    import crim_batch_driver as drv
-    src = os.path.join(ROOT, "tests", "golden", "xray_images")
-    names = sorted(f for f in os.listdir(src) if f.endswith(".jpg"))
-    imgs = np.stack([drv.read_bgr(os.path.join(src, n)) for n in names])
+    import zlib
+    z = np.load(os.path.join(ROOT, "tests", "golden", "xray_images", "decoded_bgr.npz"))
+    names = [str(n) for n in z["names"]]
+    imgs = z["bgr"]                    # the JPEGs as Pillow decoded them when the expected results were made
+    with open(os.path.join(ROOT, "tests", "golden", "xray_dataset_expected.json")) as f:
+        want = json.load(f)
     B = len(names)
     pin_in = capi.pinned_empty(imgs.shape)
     pin_in[:] = imgs
@@ -207,6 +318,8 @@ def config_dataset(capi, device, steps):
                 step()
             dt = (time.perf_counter() - t0) / steps
             iters = np.array([eng.iterations(i) for i in range(B)])
+        same = sum(int(zlib.crc32(out[i].tobytes()) == want[n]["crc32_out"] and int(iters[i]) == want[n]["iterations"])
+                   for i, n in enumerate(names))
         roof, evals_s = search_roofline(capi, 256, 256, 9, B, lambda e: e.upload_automask(imgs, dilation_size=4),
                                         "k_search_pipe<9, true>", 5, False, device)
         # the stage that follows the inpainter in the reference's pipeline (filter_noise, utils.py:106-138)
@@ -224,6 +337,8 @@ def config_dataset(capi, device, steps):
             "images": B, "images_per_s_incl_host_io": B / dt, "ms_per_batch": 1e3 * dt,
             "iterations_per_image_mean": float(iters.mean()), "iterations_per_image_max": int(iters.max()),
             "us_per_lockstep_iteration": 1e6 * dt / int(iters.max()),
+            "outputs_identical_to_cpu_oracle": "%d of %d (CRC-32 of the output image and iteration count against "
+                                               "tests/golden/xray_dataset_expected.json, checked outside the timed region)" % (same, B),
             "evals_per_s_per_gpu": evals_s, "roofline": roof,
             "next_stage_filter_noise": {
                 "what": "filter_noise(median 3, non-local means h=7 / hColor=1, template 9, search 31, sharpening) "
@@ -233,7 +348,7 @@ def config_dataset(capi, device, steps):
                 "window_differences_per_s": B * 256 * 256 * 961 * 81 * 3 / nf_dt}}
 
 
-def config_512_batch(capi, torch, device, imgs, masks, steps):
+def config_512_batch(capi, torch, device, imgs, masks, steps, oracle_crcs=None):
     """configs[2] on one GPU: 800 synthetic 512x512 false-colour images, 10 % masks, patch 9."""
     B = len(imgs)
     d_img = torch.from_numpy(imgs).cuda()
@@ -253,6 +368,12 @@ def config_512_batch(capi, torch, device, imgs, masks, steps):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
         iters = np.array([eng.iterations(i) for i in range(B)])
+        check = None
+        if oracle_crcs:
+            import zlib
+            got = eng.download(0, len(oracle_crcs))[0]
+            check = "%d of %d" % (sum(int(zlib.crc32(got[i].tobytes()) == c) for i, c in enumerate(oracle_crcs)),
+                                  len(oracle_crcs))
     roof, evals_s = search_roofline(
         capi, 512, 512, 9, B, lambda e: e.upload_device(d_img.data_ptr(), d_mask.data_ptr()),
         "k_search_pipe<9, true>", 5, True, device, max_iters=200)
@@ -261,6 +382,9 @@ def config_512_batch(capi, torch, device, imgs, masks, steps):
                         "patch_size 9, one lock-step batch, inputs and outputs resident in HBM" % B,
             "images": B, "images_per_s": B / dt, "ms_per_batch": 1e3 * dt,
             "iterations_per_image_mean": float(iters.mean()), "iterations_per_image_max": int(iters.max()),
+            "outputs_identical_to_cpu_oracle": check,
+            "outputs_check_note": "the first images of the batch, filled by the C oracle on the host cores before the "
+                                  "GPU was touched; compared outside the timed region",
             "evals_per_s_per_gpu": evals_s, "roofline": roof,
             "roofline_note": "search launches of the first 200 lock-step iterations, each alone on the GPU"}
 
@@ -315,10 +439,12 @@ def config_large(capi, device, side, patch, config_index, profile_iters=1500):
     windows = (side - P + 1) ** 2
     roof, evals_s = search_roofline(capi, side, side, patch, 1, lambda e: e.upload(img, mask),
                                     "k_search_pipe<%d, true>" % P, 5, False, device, max_iters=profile_iters)
+    split = launch_split(capi, side, side, patch, lambda e: e.upload(img, mask), device, 3000)
     return {"workload": "BASELINE configs[%d]: one %dx%d false-colour image, centred %dx%d hole (25 %%), "
                         "patch_size %d, filled to completion" % (config_index, side, side, side // 2, side // 2, patch),
             "iterations": int(it), "seconds": dt, "images_per_s": 1.0 / dt,
             "us_per_iteration": 1e6 * dt / max(it, 1),
+            "launches_us": split,
             "evals_per_s_whole_iteration": windows * it / dt,
             "evals_per_s_per_gpu": evals_s,
             "search_share_of_iteration": roof["avg_launch_us"] / (1e6 * dt / max(it, 1)),
@@ -426,7 +552,10 @@ def main():
     # here -- before this process touches the GPU -- and released through a file further down.
     split_proc = None
     split_dir = None
-    if (world > 1 or 4 in want) and not args.no_split:
+    # (under a profiler the process must stay alone: its children would inherit the profiler's preload)
+    profiled = any(k in os.environ for k in ("ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY_CTOR")) or \
+        "rocprof" in os.environ.get("LD_PRELOAD", "")
+    if (world > 1 or 4 in want) and not args.no_split and not profiled:
         import crim_split_worker as sw
         split_dir = os.path.join(os.environ.get("TMPDIR", "/tmp"),
                                  "crim_split_%s_%s" % (os.environ.get("MASTER_PORT", "solo"),
@@ -436,8 +565,19 @@ def main():
             shutil.rmtree(split_dir, ignore_errors=True)
         os.makedirs(split_dir, exist_ok=True)
         dev = int(os.environ.get("BENCH_DEVICE", local_rank))
-        split_proc = sw.launch_worker(rank, world, dev, split_dir, size=4096, patch=9, iters=args.split_iters)
+        split_proc = sw.launch_worker(rank, world, dev, split_dir, size=4096, patch=9, iters=args.split_iters, wait=600.0)
+    try:
+        run_benchmark(args, rank, local_rank, world, distributed, want, B, split_proc, split_dir, profiled)
+    finally:
+        # a worker that was never released (an error above) must not sit on the GPU until its own time-out
+        if split_proc is not None and split_proc.poll() is None:
+            try:
+                split_proc.wait(timeout=5 if sys.exc_info()[0] is not None else 270)
+            except Exception:                                   # noqa: BLE001
+                split_proc.kill()
 
+
+def run_benchmark(args, rank, local_rank, world, distributed, want, B, split_proc, split_dir, profiled):
     imgs, masks = make_batch(B, H, W, CONFIG_ID, rank * B, args.colour)
     imgs512 = masks512 = None
     if 2 in want:
@@ -448,8 +588,11 @@ def main():
     # CPU baseline first (rank 0, single-GPU runs only), before this process touches the GPU:
     # the worker pool forks.
     cpu = None
+    crc512 = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(imgs, masks)
+        if imgs512 is not None:
+            crc512 = cpu_outputs_crc(imgs512, masks512, 4)
 
     import torch
     import torch.distributed as dist
@@ -558,6 +701,7 @@ def main():
                         "ops (2 per MAC) against the dense i8 MFMA peak, 243 algorithmic MAC per window")
         result["evals_per_s_per_gpu"] = evals_s
         result["roofline"] = roof
+        result["roofline_stencil"] = stencil_roofline()
     del d_img, d_mask, d_out
     torch.cuda.empty_cache()
 
@@ -581,12 +725,17 @@ def main():
         result["cpu_baseline"] = cpu
 
     if rank == 0 and world == 1 and want:
+        first_img, first_mask = imgs[0].copy(), masks[0].copy()
         del imgs, masks
         cfgs = {}
         if 0 in want:
             cfgs["configs[0]"] = config_dataset(capi, local_rank, args.steps)
         if 1 in want:
+            one, one_out = single_image(capi, local_rank, first_img, first_mask)
+            one["output_identical_to_batch_run"] = bool(gpu_first is not None and np.array_equal(one_out, gpu_first[0])) \
+                if gpu_first is not None else None
             cfgs["configs[1]"] = {"workload": result["config"]["workload"], "images_per_s": value,
+                                  "single_image": one,
                                   "images_per_s_incl_host_io": result.get("value_incl_host_io"),
                                   "iterations_per_image_mean": float(iters_per_image.mean()),
                                   "evals_per_s_per_gpu": result.get("evals_per_s_per_gpu"),
@@ -594,7 +743,7 @@ def main():
                                                ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_us")}
                                   if "roofline" in result else None}
         if 2 in want:
-            cfgs["configs[2]"] = config_512_batch(capi, torch, local_rank, imgs512, masks512, max(1, args.steps - 1))
+            cfgs["configs[2]"] = config_512_batch(capi, torch, local_rank, imgs512, masks512, max(1, args.steps - 1), crc512)
             del imgs512, masks512
             torch.cuda.empty_cache()
         if 3 in want:
@@ -604,6 +753,10 @@ def main():
             cfgs["configs[4]"] = config_large(capi, local_rank, 4096, 9, 4)
             cfgs["configs[4]"]["multi_gpu_note"] = ("one GPU; the intra-image split over N GPUs (RCCL all-gather of 16 B "
                                                     "per rank per iteration) is measured by `bench.py --gpus N`")
+        if 0 in want and not profiled:
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            cfgs["configs[0]"]["directory_driver"] = directory_driver_runs()
         result["configs"] = cfgs
 
     if distributed:
@@ -623,16 +776,13 @@ def main():
             sw.release(split_dir)
             res = sw.summarise(sw.collect(split_dir, world, 240.0))
             res["note"] = ("configs[4], %d rank(s): every rank holds a replica of the 4096x4096 image, scores its share of "
-                           "the window-origin rows and the ranks' best windows (16 B each) are exchanged by one RCCL "
-                           "all-gather per iteration; us_per_iteration is the slowest rank's, over %d iterations after "
+                           "the window-origin rows and the ranks' shares of the per-block best windows (16 B per search "
+                           "block) are put together by one in-place RCCL all-gather per iteration, captured with the "
+                           "iteration's kernels into the replayed graphs (graph_captured); us_per_iteration is the slowest rank's, over %d iterations after "
                            "32 warm-up ones; single_gpu_us_per_iteration is the unsplit engine on rank 0's GPU over the "
                            "same iterations (the crossover is where the former drops below the latter)"
                            % (world, args.split_iters))
             result.setdefault("configs", {}).setdefault("configs[4]", {})["split_rccl"] = res
-        try:
-            split_proc.wait(timeout=30 if rank == 0 else 270)
-        except Exception:                                   # noqa: BLE001
-            split_proc.kill()
         if distributed:
             dist.barrier()
 

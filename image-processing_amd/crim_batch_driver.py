@@ -2,7 +2,9 @@
 (list the ``*.jpg`` files of a directory, load each as BGR uint8, process, write the result under
 the same file name) around the reference's ``inpaint_image`` (src/utils.py:67-103), with the
 images of one shape filled as lock-step batches on the GPU and JPEG decode / encode running on
-host threads while the GPU works.
+host worker PROCESSES while the GPU works (Pillow holds the interpreter lock for part of a decode or
+encode, so threads do not scale; the workers are forked before this function first touches the GPU and
+never touch it themselves).
 
 Only the inpainting stage is run (the reference's ``process_image`` also fixes perspective,
 denoises and adjusts contrast; those stages are not part of this package).  Files are read and
@@ -14,7 +16,7 @@ different JPEG decoders.
 import os
 import sys
 import time
-from concurrent.futures import ThreadPoolExecutor
+from concurrent.futures import ProcessPoolExecutor, ThreadPoolExecutor
 
 import numpy as np
 
@@ -80,14 +82,33 @@ class _ShapeQueue:
         return res
 
 
-def inpaint_directory(path_to_images, results_dir, patch_size=9, dilation_size=4, batch=64, device=0,
-                      io_threads=8, start_from=None, log=None, make_engine=None, reader=read_bgr,
-                      writer=write_bgr):
+def _io_worker_ready(_):
+    return os.getpid()
+
+
+def default_io_workers():
+    """Worker processes for JPEG coding: the cores this process may use, at most 16."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    env = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    if env > 1:
+        n = min(n, env)
+    return max(1, min(16, n))
+
+
+def inpaint_directory(path_to_images, results_dir, patch_size=9, dilation_size=4, batch=256, device=0,
+                      io_threads=None, start_from=None, log=None, make_engine=None, reader=read_bgr,
+                      writer=write_bgr, io_processes=None):
     """Inpaints every '*.jpg' of `path_to_images` into `results_dir` under the same name.
 
-    Decoding runs ahead on `io_threads` host threads, encoding and writing trail behind on the same
-    pool, and the calling thread only feeds the GPU.  Returns a dict with the counts and the wall
-    time.  `make_engine(H, W, batch)`, `reader` and `writer` exist for tests.
+    Decoding runs ahead on `io_processes` worker processes (default: one per usable core, at most 16),
+    encoding and writing trail behind on the same pool, and the calling thread only feeds the GPU.  With
+    io_processes=0, or a `reader` / `writer` other than this module's (tests pass closures, which cannot
+    cross a process boundary), `io_threads` host threads do the coding instead.  A batch smaller than
+    `batch` images of one shape is padded with images that have nothing to fill.  Returns a dict with the
+    counts and the wall time.  `make_engine(H, W, batch)`, `reader` and `writer` exist for tests.
     """
     log = log or (lambda s: print(s, file=sys.stderr))
     if make_engine is None:
@@ -99,7 +120,26 @@ def inpaint_directory(path_to_images, results_dir, patch_size=9, dilation_size=4
     done = failed = 0
     queues = {}
     writes = []
-    with ThreadPoolExecutor(max_workers=max(1, io_threads)) as pool:
+    if io_processes is None:
+        io_processes = default_io_workers() if (reader is read_bgr and writer is write_bgr and io_threads is None) else 0
+    if io_processes > 0 and not (reader is read_bgr and writer is write_bgr):
+        raise ValueError("inpaint_directory: a custom reader or writer needs io_processes=0 (threads)")
+    if io_threads is None:
+        io_threads = 8
+    if io_processes > 0:
+        import multiprocessing as mp
+        pool_cm = ProcessPoolExecutor(max_workers=io_processes, mp_context=mp.get_context("fork"))
+        nworkers = io_processes
+    else:
+        pool_cm = ThreadPoolExecutor(max_workers=max(1, io_threads))
+        nworkers = max(1, io_threads)
+    io_threads = nworkers
+    with pool_cm as pool:
+        if io_processes > 0:
+            # every worker exists before the first engine is created (a process forked later would be
+            # forked from one that holds a GPU context)
+            list(pool.map(_io_worker_ready, range(4 * nworkers)))
+
         def emit(results):
             for tag, img in results:
                 writes.append(pool.submit(writer, os.path.join(results_dir, tag), img))
@@ -153,13 +193,13 @@ def main(argv=None):
     ap.add_argument("results_dir")
     ap.add_argument("--patch-size", type=int, default=9)
     ap.add_argument("--dilation-size", type=int, default=4)
-    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--device", type=int, default=0)
-    ap.add_argument("--io-threads", type=int, default=8)
+    ap.add_argument("--io-processes", type=int, default=None, help="JPEG coding workers (default: one per core, at most 16)")
     ap.add_argument("--start-from", default=None)
     a = ap.parse_args(argv)
     st = inpaint_directory(a.path_to_images, a.results_dir, a.patch_size, a.dilation_size, a.batch,
-                           a.device, a.io_threads, a.start_from)
+                           a.device, start_from=a.start_from, io_processes=a.io_processes)
     print("%d images in %.2f s (%.1f images/s), %d failed to load" % (
         st["images"], st["seconds"], st["images"] / max(st["seconds"], 1e-9), st["failed"]))
 

@@ -98,6 +98,8 @@ def load_library():
     lib.crim_iterations.argtypes = [vp, ci, ctypes.POINTER(cl)]
     lib.crim_search_times.restype = ci
     lib.crim_search_times.argtypes = [vp, ci, vp, cl, ctypes.POINTER(cl)]
+    lib.crim_iteration_stamps.restype = ci
+    lib.crim_iteration_stamps.argtypes = [vp, ci, vp, cl, ctypes.POINTER(cl)]
     lib.crim_noalloc_bytes_needed.restype = ctypes.c_size_t
     lib.crim_noalloc_bytes_needed.argtypes = [ci, ci, ci]
     lib.crim_debug_state.restype = ci
@@ -361,6 +363,15 @@ class Engine:
         _check(load_library().crim_search_times(self._h, int(index), None, 0, ctypes.byref(n)))
         buf = np.zeros(max(n.value, 1), np.float32)
         _check(load_library().crim_search_times(self._h, int(index), buf.ctypes.data, n.value, ctypes.byref(n)))
+        return buf[:n.value]
+
+    def iteration_stamps(self, index=0):
+        """int64 [n,3] per executed iteration: 100 MHz device clock at the start of the selecting launch, at
+        the end of the selection, at the start of the update."""
+        n = ctypes.c_long()
+        _check(load_library().crim_iteration_stamps(self._h, int(index), None, 0, ctypes.byref(n)))
+        buf = np.zeros((max(n.value, 1), 3), np.int64)
+        _check(load_library().crim_iteration_stamps(self._h, int(index), buf.ctypes.data, n.value, ctypes.byref(n)))
         return buf[:n.value]
 
     def profile(self):

@@ -810,7 +810,7 @@ static int prepare(crim_engine* h) {
                         need, p.B, hipGetErrorString(te));
         }
         q.trace_cap = need;
-        if (hipMalloc((void**)&q.stime, (size_t)p.B * need * sizeof(float)) != hipSuccess) q.stime = nullptr;   // optional
+        if (hipMalloc((void**)&q.stime, (size_t)p.B * need * 3 * sizeof(long long)) != hipSuccess) q.stime = nullptr;   // optional
     }
     const bool changed = memcmp(&q, &p, sizeof(Params)) != 0;
     p = q;
@@ -1330,18 +1330,35 @@ extern "C" int crim_trace(crim_t* h, int index, crim_iter_rec* buf, long cap, lo
     return CRIM_OK;
 }
 
-extern "C" int crim_search_times(crim_t* h, int index, float* us_out, long cap, long* n) {
-    if (!h || !n) return fail(CRIM_ERR_ARG, "crim_search_times: null argument");
+extern "C" int crim_iteration_stamps(crim_t* h, int index, long long* out3, long cap, long* n) {
+    if (!h || !n) return fail(CRIM_ERR_ARG, "crim_iteration_stamps: null argument");
     const Params& p = h->prm;
-    if (index < 0 || index >= p.B) return fail(CRIM_ERR_ARG, "crim_search_times: index %d of %d", index, p.B);
+    if (index < 0 || index >= p.B) return fail(CRIM_ERR_ARG, "crim_iteration_stamps: index %d of %d", index, p.B);
     long iters = 0;
     const int rc = crim_iterations(h, index, &iters);
     if (rc) return rc;
     const long have = p.stime ? std::min(iters, p.trace_cap) : 0;
     *n = have;
     const long take = std::min(have, cap);
-    if (us_out && take > 0)
-        HIP_TRY(hipMemcpy(us_out, p.stime + (size_t)index * p.trace_cap, (size_t)take * sizeof(float), hipMemcpyDeviceToHost));
+    if (out3 && take > 0)
+        HIP_TRY(hipMemcpy(out3, p.stime + (size_t)index * p.trace_cap * 3, (size_t)take * 3 * sizeof(long long),
+                          hipMemcpyDeviceToHost));
+    return CRIM_OK;
+}
+
+extern "C" int crim_search_times(crim_t* h, int index, float* us_out, long cap, long* n) {
+    if (!h || !n) return fail(CRIM_ERR_ARG, "crim_search_times: null argument");
+    long have = 0;
+    int rc = crim_iteration_stamps(h, index, nullptr, 0, &have);
+    if (rc) return rc;
+    *n = have;
+    const long take = std::min(have, cap);
+    if (us_out && take > 0) {
+        std::vector<long long> st((size_t)take * 3);
+        rc = crim_iteration_stamps(h, index, st.data(), take, &have);
+        if (rc) return rc;
+        for (long i = 0; i < take; ++i) us_out[i] = (float)(st[3 * i + 2] - st[3 * i + 1]) * 0.01f;
+    }
     return CRIM_OK;
 }
 

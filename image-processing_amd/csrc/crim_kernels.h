@@ -1069,6 +1069,7 @@ __global__ __launch_bounds__(256) void k_select(Params p) {
     ImgState* st = p.st + b;
     Desc* d = p.desc + b;
     const int tid = threadIdx.x;
+    const long long t_start = tid == 0 ? (long long)wall_clock64() : 0;
     // Dependent memory round trips dominate this kernel, so the partial list is read together with
     // the loop state.
     const PEntry* pl = p.plist + (size_t)b * p.pgrid;
@@ -1246,6 +1247,7 @@ __global__ __launch_bounds__(256) void k_select(Params p) {
         d->cur = cur; d->iter = st_iter; d->remaining = st_remaining;
         d->tlsel = st_tlsel; d->tcount = st_tcount;
         d->t_select = (long long)wall_clock64();
+        d->t_entry = t_start;
         st->pcount = 0;
         st->scount = 0;
         st->bound = 0x7fffffff;
@@ -1954,6 +1956,7 @@ void k_search_pipe(Params p) {
         // row-major index; an empty front leaves the target at pixel 0, :216-218)
         const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
         const int H = p.H, W = p.W;
+        const long long t_start = (sub_ == 0 && tid == 0) ? (long long)wall_clock64() : 0;
         const ImgState* st = p.st + b;
         const PEntry* pl_ = p.plist + (size_t)b * p.pgrid;
         constexpr int NSPEC = 4;
@@ -2010,6 +2013,7 @@ void k_search_pipe(Params p) {
             dw->cnew = p.conf[((size_t)b * 2 + (cur ^ 1)) * ((size_t)H * W) + pos];
             dw->cur = cur; dw->iter = st_iter; dw->remaining = st_remaining;
             dw->tlsel = st_tlsel; dw->tcount = st_tcount;
+            dw->t_entry = t_start;
         }
     }
     const int ncy = SELECT ? sel.ncy : d->ncy, ncx = SELECT ? sel.ncx : d->ncx;
@@ -2899,7 +2903,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PM <= 9 ? 8
             rec.tr = d->tr; rec.tc = d->tc; rec.sy = sy; rec.sx = sx;
             rec.cost = src_cost; rec.remaining = rem;
             p.trace[(size_t)b * p.trace_cap + it] = rec;
-            if (p.stime) p.stime[(size_t)b * p.trace_cap + it] = (float)(t_entry - d->t_select) * 0.01f;
+            if (p.stime) {
+                long long* q = p.stime + ((size_t)b * p.trace_cap + it) * 3;
+                q[0] = d->t_entry; q[1] = d->t_select; q[2] = t_entry;
+            }
         }
         st->remaining = rem;
         st->iter = it + 1;

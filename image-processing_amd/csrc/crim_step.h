@@ -326,7 +326,7 @@ __device__ __forceinline__ void step_near(const Params& p, const int b, const De
     // further down would cost the chain a round trip of its own)
     const double cnew = d->cnew;
     const int d_tr = d->tr, d_tc = d->tc, d_iter = d->iter, d_rem = d->remaining - d->nfill;
-    const long long d_tsel = d->t_select;
+    const long long d_tsel = d->t_select, d_tent = d->t_entry;
     if (!live) return;
     // this wave's LDS working set, and the offset table of the fast path, while the loads travel
     PrioLds<PT> L;
@@ -496,7 +496,10 @@ __device__ __forceinline__ void step_near(const Params& p, const int b, const De
                 rec.tr = d_tr; rec.tc = d_tc; rec.sy = sy; rec.sx = sx;
                 rec.cost = bc; rec.remaining = d_rem;
                 p.trace[(size_t)b * p.trace_cap + it] = rec;
-                if (p.stime) p.stime[(size_t)b * p.trace_cap + it] = (float)(t_entry - d_tsel) * 0.01f;
+                if (p.stime) {
+                    long long* q = p.stime + ((size_t)b * p.trace_cap + it) * 3;
+                    q[0] = d_tent; q[1] = d_tsel; q[2] = t_entry;
+                }
             }
         }
     }

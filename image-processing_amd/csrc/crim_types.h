@@ -80,6 +80,7 @@ struct Desc {
     int tlsel;           // ... current tile-list buffer,
     unsigned tcount;     // ... and its length
     long long t_select;  // 100 MHz wall clock when the selection finished (the search starts here)
+    long long t_entry;   // ... and when the launch that selects started
     // Templates as byte planes, zero padded: kflat = 1 - mask, tflat = k * (Lab - 128).
     uint8_t kflat[CRIM_PMAX * CRIM_PMAX];
     int8_t tflat[3][CRIM_PMAX * CRIM_PMAX];
@@ -139,7 +140,8 @@ struct Params {
     PEntry* plist;     // [B][pgrid]
     SEntry* slist;     // [B][snx*srows] one slot per search block (row-major block rows)
     crim_iter_rec* trace;  // [B][trace_cap]
-    float* stime;          // [B][trace_cap] microseconds from the end of the selection to the start of the update
+    long long* stime;      // [B][trace_cap][3] 100 MHz wall clock per iteration: start of the selecting launch, end of the
+                           // selection, start of the update
     long long* dbg;        // diagnostic stamps (only written by -DCRIM_STAMPS builds)
     const uint16_t* gamma_tab;
     const uint16_t* cbrt_tab;

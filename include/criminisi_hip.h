@@ -186,6 +186,11 @@ int crim_iterations(crim_t* h, int index, long* n);
  * launch boundary after it; lock-step batches share the launch, so every image of a batch sees its
  * batch's time.  Kept with the per-iteration records (none under CRIM_FLAG_NO_TRACE). */
 int crim_search_times(crim_t* h, int index, float* us_out, long cap, long* n);
+/* The raw stamps behind it, three per executed iteration (ticks of the device's 100 MHz clock): start of
+ * the launch that selects the target, end of the selection, start of the update.  Differences between
+ * consecutive iterations give the time of each launch of the loop as the device saw it (measurement
+ * instrument; no counterpart in the reference). */
+int crim_iteration_stamps(crim_t* h, int index, long long* out3, long cap, long* n);
 
 /* The integer BGR->Lab tables the engine uses in place of cv2.cvtColor(..., COLOR_BGR2LAB)
  * (:225): 256-entry sRGB gamma table, 3072-entry cube-root table, 9 matrix coefficients

@@ -42,6 +42,11 @@ def main():
         res = dict(pool.map(one, names))
     with open(os.path.join(ROOT, "tests", "golden", "xray_dataset_expected.json"), "w") as f:
         json.dump(res, f, indent=0, sort_keys=True)
+    # the decoded pixels themselves, so that tests and the benchmark's output check do not depend on the
+    # JPEG decoder of the machine they run on
+    import crim_batch_driver as drv
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "xray_images", "decoded_bgr.npz"), names=np.array(names),
+                        bgr=np.stack([drv.read_bgr(os.path.join(SRC, n)) for n in names]))
     print(len(res), "images,", sum(r["iterations"] for r in res.values()), "iterations")
 
 

@@ -1,7 +1,9 @@
 #!/bin/bash
 # Separate rocprofv3 PMC passes over a short bench run (one counter group per run, no tracing
-# domains beside it).  Outputs under gpurun_out/pmc_<name>/.
+# domains beside it).  Outputs under gpurun_out/pmc_<name>/.  Usage: tools/pmc_passes.sh [kernel_stats.csv of
+# the same command: its average launch durations go into the stencil-stage summary]
 R=$GRAFT_REPO_ROOT
+KSTATS=${1:-}
 cd /tmp && export TMPDIR=/tmp
 run() {
   name=$1; shift
@@ -42,4 +44,23 @@ for k, v in summary.items():
                    "images_per_launch": 4096,   # default bench batch 8192 on 2 lanes
                    "command": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate runs) -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --configs \"\" --no-host-io --no-split"},
                   open("$R/gpurun_out/pmc_search_latest.json", "w"), indent=1)
+# the stencil stages (priority, update) with their launch durations from the kernel trace of the same command
+dur, share = {}, {}
+if "$KSTATS":
+    try:
+        for r in csv.DictReader(open("$KSTATS")):
+            k = r["Name"].split("(")[0]
+            dur[k] = float(r["AverageNs"]) / 1e3
+            share[k] = float(r["Percentage"]) / 100.0
+    except OSError:
+        pass
+sten = {}
+for k, v in summary.items():
+    if ("k_priority" in k or "k_update" in k or "k_step" in k) and "FETCH_SIZE_per_launch" in v and "WRITE_SIZE_per_launch" in v and k in dur:
+        sten[k.replace("void ", "")] = {"FETCH_SIZE_KB_per_launch": v["FETCH_SIZE_per_launch"], "WRITE_SIZE_KB_per_launch": v["WRITE_SIZE_per_launch"],
+                                        "avg_launch_us": dur[k], "share_of_gpu_time": share.get(k), "images_per_launch": 4096,
+                                        "salu_per_valu": (v["SQ_INSTS_SALU_per_launch"] / v["SQ_INSTS_VALU_per_launch"]) if v.get("SQ_INSTS_VALU_per_launch") else None}
+if sten:
+    json.dump({"kernels": sten, "command": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_* (separate runs) and --kernel-trace --stats -- python3 bench.py --configs \"\" --no-host-io --no-split --no-cpu-baseline (headline batch, 4096 images per launch)"},
+              open("$R/gpurun_out/pmc_stencil_latest.json", "w"), indent=1)
 PY

@@ -18,5 +18,5 @@ cut -c1-150 $R/gpurun_out/${TAG}_kernel_stats_headline.csv | head -12
 PER_PASS=$(python3 -c "import json; print(json.load(open('$R/gpurun_out/${TAG}_bench_headline_under_rocprofv3.json'))['roofline']['launches'])")
 python3 $R/tools/search_duration_by_phase.py $R/gpurun_out/profh_$TAG/*/*kernel_trace.csv $PER_PASS | tee $R/gpurun_out/${TAG}_search_duration_by_phase.txt
 rm -f $R/gpurun_out/profh_$TAG/*/*kernel_trace.csv
-bash $R/tools/pmc_passes.sh > $R/gpurun_out/${TAG}_pmc_totals.txt 2>&1 || exit 1
+bash $R/tools/pmc_passes.sh $R/gpurun_out/${TAG}_kernel_stats_headline.csv > $R/gpurun_out/${TAG}_pmc_totals.txt 2>&1 || exit 1
 tail -25 $R/gpurun_out/${TAG}_pmc_totals.txt
