@@ -682,7 +682,7 @@ __device__ __forceinline__ void prio_eval_tile(const Params& p, const double* s_
                                                const uint8_t* s_list, const uint8_t* s_mask, const ushort2* s_off,
                                                const int RS, const int ty0, const int tx0, const int n,
                                                const bool fresh, double* dterm, double* cnxt, const int grp,
-                                               const int l, double& bestP, int& bestI) {
+                                               const int l, double& bestP, int& bestI, const int ngroups = 64 / PG) {
     constexpr int MS = CRIM_TILE + 2;
     constexpr int NE = PT > 0 ? (PT * PT) / 8 : 1;
     // blocks of 8 in the first half of the pairwise split (all of them when there is no split)
@@ -692,7 +692,7 @@ __device__ __forceinline__ void prio_eval_tile(const Params& p, const double* s_
     const int ry0 = ty0 - half, rx0 = tx0 - half;
     View<double> vconf; vconf.base = (const unsigned char*)s_cf; vconf.pitch = RS; vconf.oy = ry0; vconf.ox = rx0; vconf.stride = 8;
     View<int> vgrad; vgrad.base = (const unsigned char*)s_gk + 4; vgrad.pitch = RS; vgrad.oy = ry0; vgrad.ox = rx0; vgrad.stride = 8;
-    for (int e = grp; e < n; e += 64 / PG) {
+    for (int e = grp; e < n; e += ngroups) {   // ngroups: lane groups that share the tile's front pixels
         const int pi = s_list[e];
         const int py = pi >> 4, px = pi & 15;
         const int fy = ty0 + py, fx = tx0 + px;
@@ -954,9 +954,16 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
         const int xx = imin(imax(rx0 + scol, 0), W - 1);
         const bool fresh = ty0 <= dy1 && ty0 + CRIM_TILE - 1 >= dy0 && tx0 <= dx1 && tx0 + CRIM_TILE - 1 >= dx0;
         bool first = true, stale = false;
+        // With a compile-time patch edge the staged region's edge RS is even and a lane's rows srow + 2k
+        // (one batch) never pass it: the stores below are then under ONE lane predicate (scol < RS), not
+        // one per row -- every separately predicated store costs a save / restore of the execution mask
+        // and a branch.
+        constexpr bool ROWS_FIT = PT > 0;
+        static_assert(PT == 0 || (CRIM_TILE + PT - 1) % 2 == 0, "odd patch edges only");
         for (int rb = srow; rb < RS; rb += NRB * rpp) {
             double cv[NRB];
             int gv[NRB];
+            unsigned gidx[NRB];
 #pragma unroll
             for (int k = 0; k < NRB; ++k) {
                 const int row = imin(rb + k * rpp, RS - 1);
@@ -965,7 +972,11 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
                 // (24-bit multiply: one full-rate instruction; H, W < 2^24)
                 const unsigned idx = __umul24((unsigned)yy, (unsigned)W) + (unsigned)xx;
                 cv[k] = *(const double*)((const char*)ccur + (size_t)(idx * 8u));
-                if (fresh) gv[k] = *(const int*)((const char*)grad + (size_t)(idx * 4u));
+                gidx[k] = idx * 4u;
+            }
+            if (fresh) {   // (one wave-uniform branch for all rows)
+#pragma unroll
+                for (int k = 0; k < NRB; ++k) gv[k] = *(const int*)((const char*)grad + (size_t)gidx[k]);
             }
             if (first) {
                 first = false;
@@ -976,21 +987,23 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
                 }
             }
             if (fresh) {
+                if (scol < RS) {
 #pragma unroll
-                for (int k = 0; k < NRB; ++k) {
-                    const int row = rb + k * rpp;
-                    if (row < RS && scol < RS) {
-                        const int gy2 = (int)(short)(gv[k] & 0xffff), gx2 = gv[k] >> 16;
-                        s_cf[row * RS + scol] = cv[k];
-                        s_gk[row * RS + scol] = make_uint2((uint32_t)(gy2 * gy2 + gx2 * gx2) << 10, (uint32_t)gv[k]);
+                    for (int k = 0; k < NRB; ++k) {
+                        const int row = rb + k * rpp;
+                        if (ROWS_FIT || row < RS) {
+                            const int gy2 = (int)(short)(gv[k] & 0xffff), gx2 = gv[k] >> 16;
+                            s_cf[row * RS + scol] = cv[k];
+                            s_gk[row * RS + scol] = make_uint2((uint32_t)(gy2 * gy2 + gx2 * gx2) << 10, (uint32_t)gv[k]);
+                        }
                     }
                 }
-            } else {
+            } else if (scol < RS) {
                 // the confidence plane only
 #pragma unroll
                 for (int k = 0; k < NRB; ++k) {
                     const int row = rb + k * rpp;
-                    if (row < RS && scol < RS) s_cf[row * RS + scol] = cv[k];
+                    if (ROWS_FIT || row < RS) s_cf[row * RS + scol] = cv[k];
                 }
             }
         }
@@ -1002,11 +1015,11 @@ __global__ __launch_bounds__(64) void k_priority(Params p) {
         for (int pass = 0; pass < CRIM_TILE * CRIM_TILE / 64; ++pass) {
             const int pi = pass * 64 + lane;
             const int py = pi >> 4, px = pi & 15;
-            bool isf = false;
-            if (ty0 + py < H && tx0 + px < W) {
-                const uint8_t* m0 = s_mask + py * MS + px;   // top-left of the 3x3 neighbourhood
-                isf = m0[MS + 1] == 0 && (m0[0] + m0[2] + m0[2 * MS] + m0[2 * MS + 2]) > 0;
-            }
+            // (the staged mask covers the whole tile grown by one pixel, also beyond the image: read without
+            // a branch, the image bounds enter as a flag)
+            const uint8_t* m0 = s_mask + py * MS + px;   // top-left of the 3x3 neighbourhood
+            const bool isf = (ty0 + py < H) & (tx0 + px < W) & (m0[MS + 1] == 0) &
+                             ((m0[0] + m0[2] + m0[2 * MS] + m0[2 * MS + 2]) > 0);
             const unsigned long long bal = __ballot(isf);
             if (isf) s_list[n + __popcll(bal & ((1ull << lane) - 1ull))] = (uint8_t)pi;
             n += __popcll(bal);

@@ -17,10 +17,11 @@
 //
 // Block kinds of image b (p.kblocks blocks per image):
 //   0          bookkeeping: mask, confidence buffers, validity maps, tile counts and list, loop state
-//   1 .. 3     near tiles 4 (k - 1) .. 4 (k - 1) + 3, one per wave; block 3 also copies the pixels,
+//   1 .. 9     near tile k - 1, its four waves sharing the tile; block 9 also copies the pixels,
 //              rewrites the gradient around the patch and records the iteration
-//   4 ..       far tiles: wave w of these blocks walks entries w, w + p.nfar, ... of the tile list
-// Every wave of kinds 1.. owns one slot of the image's priority list, as the waves of k_priority do.
+//   10 ..      far tiles: wave w of these blocks walks entries w, w + p.nfar, ... of the tile list
+// Every near block and every far wave owns one slot of the image's priority list, as the waves of
+// k_priority do.
 #pragma once
 
 // Orders the LDS accesses of ONE wave (the waves of a k_step block work on different tiles and must not
@@ -38,8 +39,6 @@ struct PrioLds {
     static constexpr int RS = CRIM_TILE + PT - 1;       // edge of the staged region
     static constexpr int MS = CRIM_TILE + 2;            // edge of the staged mask
     static constexpr int NE = (PT * PT) / 8;
-    static constexpr int NRB = (RS + 1) / 2;            // staged rows per lane (two rows of up to 32 columns per sweep)
-    static constexpr int MSW = (MS + 1) / 2;
     double* s_cf;
     uint2* s_gk;
     uint8_t* s_list;
@@ -53,8 +52,8 @@ struct PrioLds {
         s_off = (ushort2*)(base + ((RS * RS * 16 + CRIM_TILE * CRIM_TILE + MS * MS + 3) & ~3));
     }
     // per-lane-of-group table of record offsets of the fast path (see k_priority)
-    __device__ __forceinline__ void fill_offsets(int lane) const {
-        for (int t = lane; t < PG * NE; t += 64) {
+    __device__ __forceinline__ void fill_offsets(int lane, int nthreads = 64) const {
+        for (int t = lane; t < PG * NE; t += nthreads) {
             const int ll = t / NE, i = t - ll * NE;
             ushort2 o;
             {
@@ -72,14 +71,19 @@ struct PrioLds {
     }
 };
 
-// The fields of one tile on their way from memory to a wave's LDS: requested by issue(), written by
-// commit() (with the pending update applied when OVR), so that other work can pass in between.
-template <int PT>
+// The fields of one tile on their way from memory to LDS: requested by issue(), written by commit() (with
+// the pending update applied when OVR), so that other work can pass in between.  NW waves share the tile
+// (thread index t = 0 .. 64 NW - 1): a sweep of theirs covers 2 NW rows of up to 32 columns.
+template <int PT, int NW = 1>
 struct TileStage {
     using L = PrioLds<PT>;
-    double cv[L::NRB];
-    int gv[L::NRB];
-    uint8_t mv[L::MSW];
+    static constexpr int RPS = 2 * NW;                          // rows per sweep
+    static constexpr int NRB = (L::RS + RPS - 1) / RPS;         // sweeps over the staged region
+    static constexpr int MSW = (L::MS + RPS - 1) / RPS;         // sweeps over the staged mask
+    static constexpr bool ROWS_FIT = L::RS % RPS == 0, MROWS_FIT = L::MS % RPS == 0;
+    double cv[NRB];
+    int gv[NRB];
+    uint8_t mv[MSW];
     int ty0, tx0;
 
     __device__ __forceinline__ static int refl(int v, int n) {   // reflect101 of v in [-1, n]: -1 -> 1, n -> n - 2
@@ -95,14 +99,14 @@ struct TileStage {
         ty0 = tY * CRIM_TILE; tx0 = tX * CRIM_TILE;
         const unsigned mx = (unsigned)refl(tx0 - 1 + imin(lane & 31, L::MS - 1), W);
 #pragma unroll
-        for (int k = 0; k < L::MSW; ++k) {
-            const int my = refl(ty0 - 1 + 2 * k + (lane >> 5), H);
+        for (int k = 0; k < MSW; ++k) {
+            const int my = refl(ty0 - 1 + imin(RPS * k + (lane >> 5), L::MS - 1), H);
             mv[k] = mask[__umul24((unsigned)my, (unsigned)W) + mx];
         }
         const int xx = imin(imax(tx0 - half + (lane & 31), 0), W - 1);
 #pragma unroll
-        for (int k = 0; k < L::NRB; ++k) {
-            const int row = imin((lane >> 5) + 2 * k, L::RS - 1);
+        for (int k = 0; k < NRB; ++k) {
+            const int row = imin((lane >> 5) + RPS * k, L::RS - 1);
             const int yy = imin(imax(ty0 - half + row, 0), H - 1);
             const unsigned idx = __umul24((unsigned)yy, (unsigned)W) + (unsigned)xx;
             cv[k] = *(const double*)((const char*)conf + (size_t)(idx * 8u));
@@ -119,43 +123,46 @@ struct PatchOverride {
     const int* ngrad;         // LDS: packed gradient after the fill over the patch grown by one pixel; row length patch edge + 2
 };
 
-template <int PT, bool GRAD, bool OVR>
-__device__ __forceinline__ void tile_commit(const Params& p, const TileStage<PT>& st, const PrioLds<PT>& w,
+template <int PT, bool GRAD, bool OVR, int NW = 1>
+__device__ __forceinline__ void tile_commit(const Params& p, const TileStage<PT, NW>& st, const PrioLds<PT>& w,
                                             const PatchOverride& ov, int lane) {
     using L = PrioLds<PT>;
+    using S = TileStage<PT, NW>;
     const int H = p.H, W = p.W, half = p.half;
     if ((lane & 31) < L::MS) {
-        const int mx = TileStage<PT>::refl(st.tx0 - 1 + imin(lane & 31, L::MS - 1), W);
+        const int mx = S::refl(st.tx0 - 1 + imin(lane & 31, L::MS - 1), W);
 #pragma unroll
-        for (int k = 0; k < L::MSW; ++k) {
+        for (int k = 0; k < S::MSW; ++k) {
             uint8_t m = st.mv[k];
+            const int mrow = S::RPS * k + (lane >> 5);
             if (OVR) {
-                const int my = TileStage<PT>::refl(st.ty0 - 1 + 2 * k + (lane >> 5), H);
+                const int my = S::refl(st.ty0 - 1 + imin(mrow, L::MS - 1), H);
                 if (my >= ov.r0 && my < ov.r0 + ov.ph && mx >= ov.c0 && mx < ov.c0 + ov.pw) m = 0;
             }
-            // (rows beyond the staged mask -- MS is even, so there are none -- would be dropped here)
-            if (2 * k + (lane >> 5) < L::MS) w.s_mask[(2 * k + (lane >> 5)) * L::MS + (lane & 31)] = m;
+            if (S::MROWS_FIT || mrow < L::MS) w.s_mask[mrow * L::MS + (lane & 31)] = m;
         }
     }
     const int scol = lane & 31;
     const int xx = imin(imax(st.tx0 - half + scol, 0), W - 1);
     // the override tables are read for every row first (from clamped positions, all reads in flight
     // together), and applied afterwards
-    uint8_t okf[OVR ? L::NRB : 1];
+    uint8_t okf[OVR ? S::NRB : 1];
     if (OVR) {
         const int j = xx - ov.c0;
         const int jk = imin(imax(j, 0), ov.pw - 1);
 #pragma unroll
-        for (int k = 0; k < L::NRB; ++k) {
-            const int yy = imin(imax(st.ty0 - half + (lane >> 5) + 2 * k, 0), H - 1);
+        for (int k = 0; k < S::NRB; ++k) {
+            const int yy = imin(imax(st.ty0 - half + imin((lane >> 5) + S::RPS * k, L::RS - 1), 0), H - 1);
             const int i = yy - ov.r0;
             okf[k] = ov.kflat[imin(imax(i, 0), ov.ph - 1) * PT + jk];
         }
     }
+    static_assert(L::RS % 2 == 0, "with one wave a lane's rows (lane >> 5) + 2k stay inside the staged region");
+    if (scol < L::RS) {   // one lane predicate for all rows
 #pragma unroll
-    for (int k = 0; k < L::NRB; ++k) {
-        const int row = (lane >> 5) + 2 * k;
-        if (row < L::RS && scol < L::RS) {
+    for (int k = 0; k < S::NRB; ++k) {
+        const int row = (lane >> 5) + S::RPS * k;
+        if (S::ROWS_FIT || row < L::RS) {
             double c = st.cv[k];
             int g = GRAD ? st.gv[k] : 0;
             if (OVR) {
@@ -170,6 +177,7 @@ __device__ __forceinline__ void tile_commit(const Params& p, const TileStage<PT>
             }
         }
     }
+    }
 }
 
 // The staged gradient records of the pixels within one pixel of the patch, rewritten from the gradient
@@ -177,13 +185,13 @@ __device__ __forceinline__ void tile_commit(const Params& p, const TileStage<PT>
 // with the mask and confidence overrides alone, so that it can run before the source window is known.
 template <int PT>
 __device__ __forceinline__ void tile_patch_gradient(const Params& p, int ty0, int tx0, const PrioLds<PT>& w,
-                                                    const PatchOverride& ov, int lane) {
+                                                    const PatchOverride& ov, int lane, int nthreads = 64) {
     using L = PrioLds<PT>;
     const int H = p.H, W = p.W, half = p.half;
     const int bh = ov.ph + 2, bw = ov.pw + 2;
     // Staged record (row, col) holds the pixel at the CLAMPED position (ty0 - half + row, tx0 - half + col);
     // records beyond the image are never read, so only in-image pixels are visited.
-    for (int e = lane; e < bh * bw; e += 64) {
+    for (int e = lane; e < bh * bw; e += nthreads) {
         const int i = e / bw, j = e - i * bw;
         const int yy = ov.r0 - 1 + i, xx = ov.c0 - 1 + j;
         const int row = yy - (ty0 - half), col = xx - (tx0 - half);
@@ -203,16 +211,40 @@ __device__ __forceinline__ int tile_front_list(const Params& p, const PrioLds<PT
     for (int pass = 0; pass < CRIM_TILE * CRIM_TILE / 64; ++pass) {
         const int pi = pass * 64 + lane;
         const int py = pi >> 4, px = pi & 15;
-        bool isf = false;
-        if (ty0 + py < p.H && tx0 + px < p.W) {
-            const uint8_t* m0 = w.s_mask + py * L::MS + px;
-            isf = m0[L::MS + 1] == 0 && (m0[0] + m0[2] + m0[2 * L::MS] + m0[2 * L::MS + 2]) > 0;
-        }
+        const uint8_t* m0 = w.s_mask + py * L::MS + px;
+        const bool isf = (ty0 + py < p.H) & (tx0 + px < p.W) & (m0[L::MS + 1] == 0) &
+                         ((m0[0] + m0[2] + m0[2 * L::MS] + m0[2 * L::MS + 2]) > 0);
         const unsigned long long bal = __ballot(isf);
         if (isf) w.s_list[n + __popcll(bal & ((1ull << lane) - 1ull))] = (uint8_t)pi;
         n += __popcll(bal);
     }
     return n;
+}
+
+// The same by the four waves of a block, each taking 64 of the tile's 256 pixels; s_cnt: 4 ints of LDS.
+// Ends with the block in step (every thread returns the total).
+template <int PT>
+__device__ __forceinline__ int tile_front_list_block(const Params& p, const PrioLds<PT>& w, int ty0, int tx0, int tid,
+                                                     int* s_cnt) {
+    using L = PrioLds<PT>;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int py = tid >> 4, px = tid & 15;
+    const uint8_t* m0 = w.s_mask + py * L::MS + px;
+    const bool isf = (ty0 + py < p.H) & (tx0 + px < p.W) & (m0[L::MS + 1] == 0) &
+                     ((m0[0] + m0[2] + m0[2 * L::MS] + m0[2 * L::MS + 2]) > 0);
+    const unsigned long long bal = __ballot(isf);
+    if (lane == 0) s_cnt[wv] = __popcll(bal);
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = s_cnt[k];
+        before += k < wv ? c : 0;
+        total += c;
+    }
+    if (isf) w.s_list[before + __popcll(bal & ((1ull << lane) - 1ull))] = (uint8_t)tid;
+    __syncthreads();
+    return total;
 }
 
 __device__ __forceinline__ void emit_priority(const Params& p, int b, int slot, double bestP, int bestI, int lane) {
@@ -289,8 +321,13 @@ __device__ __forceinline__ void step_far(const Params& p, const int b, const Des
 template <int PT>
 __device__ __forceinline__ void step_near(const Params& p, const int b, const Desc* __restrict__ d, const int nblock,
                                           unsigned char* smem) {
-    // the near block that also copies the pixels: the last one, whose four waves share a single tile
-    constexpr int COPY_BLOCK = (CRIM_NEAR_TILES + 3) / 4 - 1;
+    // One near tile per block, its four waves sharing the tile.  The block that also copies the pixels:
+    // the last one, whose tile (the far corner of the 3 x 3) is the one least often in use.
+    constexpr int COPY_BLOCK = CRIM_NEAR_TILES - 1;
+    constexpr int NW = 4;
+    __shared__ int s_cnt[4];
+    __shared__ double s_bp[4];
+    __shared__ int s_bi[4];
     constexpr int GR = PT + 4;       // grey region: the patch grown by two pixels
     constexpr int NG = PT + 2;       // gradient region: the patch grown by one pixel
     __shared__ double s_c[4];
@@ -304,7 +341,7 @@ __device__ __forceinline__ void step_near(const Params& p, const int b, const De
     const size_t HW = (size_t)H * W;
     const long long t_entry = (nblock == COPY_BLOCK && tid == 0) ? (long long)wall_clock64() : 0;
 
-    STAMP_AT(1, 40);
+    STAMP_AT(5, 40);
     // Load batch 1: the search's per-block results (as k_update reads them) and the descriptor.
     const SEntry* sl = p.slist + (size_t)b * p.snx * p.srows;
     const int scols = p.scols;
@@ -328,10 +365,10 @@ __device__ __forceinline__ void step_near(const Params& p, const int b, const De
     const int d_tr = d->tr, d_tc = d->tc, d_iter = d->iter, d_rem = d->remaining - d->nfill;
     const long long d_tsel = d->t_select, d_tent = d->t_entry;
     if (!live) return;
-    // this wave's LDS working set, and the offset table of the fast path, while the loads travel
+    // the tile's LDS working set, and the offset table of the fast path, while the loads travel
     PrioLds<PT> L;
-    L.carve(smem + (size_t)wv * p.plds);
-    L.fill_offsets(lane);
+    L.carve(smem);
+    L.fill_offsets(tid, 256);
 
     uint8_t* mask = p.mask + b * HW;
     uint8_t* bgr = p.bgr + b * HW * 3;
@@ -344,13 +381,18 @@ __device__ __forceinline__ void step_near(const Params& p, const int b, const De
 
     // Load batch 2 (needs the descriptor): this wave's tile, and the grey values and the mask around the
     // patch.  Everything unconditional, from clamped positions.
-    const int t = 4 * nblock + wv;
+    const int t = nblock;
     const int ny0 = imax(r0 - 1 - half, 0) / CRIM_TILE, nx0 = imax(c0 - 1 - half, 0) / CRIM_TILE;
     const int ny1 = imin(r0 + ph + half, H - 1) / CRIM_TILE, nx1 = imin(c0 + pw + half, W - 1) / CRIM_TILE;
     const int tY = ny0 + t / CRIM_NEAR_SPAN, tX = nx0 + t % CRIM_NEAR_SPAN;
-    const bool active = t < CRIM_NEAR_TILES && tY <= ny1 && tX <= nx1;   // wave-uniform
-    TileStage<PT> stg;
-    stg.template issue<true>(p, imin(tY, p.tny - 1) * p.tnx + imin(tX, p.tnx - 1), cread, grad, mask, lane);
+    const bool active = tY <= ny1 && tX <= nx1;   // block-uniform
+    if (!active && nblock != COPY_BLOCK) {
+        // nothing of the next front can lie here: the slot is emptied and the block is done
+        if (wv == 0) emit_priority(p, b, t, -1.0, 0x7fffffff, lane);
+        return;
+    }
+    TileStage<PT, NW> stg;
+    stg.template issue<true>(p, imin(tY, p.tny - 1) * p.tnx + imin(tX, p.tnx - 1), cread, grad, mask, tid);
     constexpr int NGB = (GR * GR + 255) / 256;
     const int gr0 = r0 - 2, gc0 = c0 - 2, grh = ph + 4, grw = pw + 4;
     uint8_t gm[NGB], gg[NGB];
@@ -400,7 +442,7 @@ __device__ __forceinline__ void step_near(const Params& p, const int b, const De
     // no admissible window: every cost is +inf and np.argmin returns index 0
     const unsigned src = (bi == 0xffffffffu) ? 0u : bi;
     const int sy = (int)(src / (unsigned)ncx), sx = (int)(src % (unsigned)ncx);
-    STAMP_AT(1, 41);
+    STAMP_AT(5, 41);
 
     // Load batch 3 (needs the source position): the source pixels, one per thread (the copying block: all
     // of a pixel; the others only need the grey value).  Requested now, used further down.
@@ -424,12 +466,12 @@ __device__ __forceinline__ void step_near(const Params& p, const int b, const De
     PatchOverride ov;
     ov.r0 = r0; ov.c0 = c0; ov.ph = ph; ov.pw = pw; ov.cnew = cnew; ov.kflat = s_kf; ov.ngrad = s_ng;
     int nf = 0;
-    if (active) {
-        tile_commit<PT, true, true>(p, stg, L, ov, lane);
-        wave_lds_sync();
-        nf = tile_front_list<PT>(p, L, stg.ty0, stg.tx0, lane);
+    if (active) {   // (block-uniform: the barriers inside are reached by every thread)
+        tile_commit<PT, true, true, NW>(p, stg, L, ov, tid);
+        __syncthreads();
+        nf = tile_front_list_block<PT>(p, L, stg.ty0, stg.tx0, tid, s_cnt);
     }
-    STAMP_AT(1, 44);
+    STAMP_AT(5, 44);
     if (has_src) {
         if (nblock == COPY_BLOCK) {
 #pragma unroll
@@ -453,7 +495,7 @@ __device__ __forceinline__ void step_near(const Params& p, const int b, const De
         s_g[i * GR + j] = v;
     }
     __syncthreads();
-    STAMP_AT(1, 42);
+    STAMP_AT(5, 42);
     // ---- gradient within one pixel of the patch (np.gradient, :174)
     const int uh = ph + 2, uw = pw + 2;
     for (int e = tid; e < uh * uw; e += 256) {
@@ -504,21 +546,32 @@ __device__ __forceinline__ void step_near(const Params& p, const int b, const De
         }
     }
     __syncthreads();   // s_ng is complete
-    STAMP_AT(1, 43);
+    STAMP_AT(5, 43);
 
     // ---- the staged gradient gets the update's part, then the front pixels are evaluated
     double bestP = -1.0;
     int bestI = 0x7fffffff;
     if (active) {
-        tile_patch_gradient<PT>(p, stg.ty0, stg.tx0, L, ov, lane);
-        wave_lds_sync();
-        STAMP_AT(1, 45);
+        tile_patch_gradient<PT>(p, stg.ty0, stg.tx0, L, ov, tid, 256);
+        __syncthreads();
+        STAMP_AT(5, 45);
         prio_eval_tile<PT>(p, L.s_cf, L.s_gk, L.s_list, L.s_mask, L.s_off, PrioLds<PT>::RS, stg.ty0, stg.tx0, nf, true,
-                           p.dterm + b * HW, cwrite, lane / PG, lane % PG, bestP, bestI);
+                           p.dterm + b * HW, cwrite, tid / PG, tid % PG, bestP, bestI, 256 / PG);
     }
-    STAMP_AT(1, 46);
-    if (t < CRIM_NEAR_TILES) emit_priority(p, b, t, bestP, bestI, lane);
-    STAMP_AT(1, 47);
+    STAMP_AT(5, 46);
+    // the block's best: every wave's, then the first thread's pick
+    wave_best_pair(bestP, bestI, [](double pa, int ia, double pb, int ib) { return better_prio(pa, ia, pb, ib); });
+    if (lane == 0) { s_bp[wv] = bestP; s_bi[wv] = bestI; }
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 1; k < 4; ++k)
+            if (better_prio(s_bp[k], s_bi[k], bestP, bestI)) { bestP = s_bp[k]; bestI = s_bi[k]; }
+        PEntry e;
+        e.prio = bestP; e.pos = bestI; e.pad = 0;
+        p.plist[(size_t)b * p.pgrid + t] = e;
+    }
+    STAMP_AT(5, 47);
 }
 
 // ---- bookkeeping -------------------------------------------------------------------------------
@@ -784,11 +837,11 @@ __global__ __launch_bounds__(256) void k_step(Params p) {
     const int b = p.b0 + img_;
     const Desc* __restrict__ d = p.desc + b;
     // (the near blocks request the search's results before they look at anything else)
-    if (sub >= 1 && sub <= (CRIM_NEAR_TILES + 3) / 4) {
+    if (sub >= 1 && sub <= CRIM_NEAR_TILES) {
         step_near<P>(p, b, d, sub - 1, smem);
         return;
     }
     if (!d->live) return;   // written by this iteration's search launch
     if (sub == 0) step_book<P>(p, b, d);
-    else step_far<P>(p, b, d, sub - 1 - (CRIM_NEAR_TILES + 3) / 4, smem);
+    else step_far<P>(p, b, d, sub - 1 - CRIM_NEAR_TILES, smem);
 }

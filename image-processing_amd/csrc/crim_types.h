@@ -117,7 +117,7 @@ struct Params {
                   // updates the image and evaluates the next iteration's priorities (k_step)
     int nfar;     // k_step: waves per image that walk the tile list (slots CRIM_NEAR_TILES ..)
     int plds;     // bytes of LDS one priority wave works in
-    int kblocks;  // k_step: blocks per image (1 bookkeeping + 3 near + nfar / 4 far)
+    int kblocks;  // k_step: blocks per image (1 bookkeeping + 9 near + nfar / 4 far)
     int generic;  // use the unspecialised search kernel
     int dot4;     // use the vector dot-product search kernel instead of the matrix-core one
     int chroma;   // some uploaded image is not grey: the matrix-core search stages all five planes
