@@ -1769,8 +1769,23 @@ int filter_noise_device(int count, int H, int W, const uint8_t* d_in, uint8_t* d
     }
     // length of the tables' non-zero prefix: all a window distance can reach with a weight
     auto prefix = [](const std::vector<int>& w) { size_t k = w.size(); while (k > 0 && w[k - 1] == 0) --k; return (int)k; };
-    hipLaunchKernelGGL(k_nf_nlm<1>, grid, block, 0, s, sc.l0, sc.l1, H, W, sc.wl, prefix(wl), shift_l);
-    hipLaunchKernelGGL(k_nf_nlm<2>, grid, block, 0, s, sc.ab0, sc.ab1, H, W, sc.wab, prefix(wab), shift_ab);
+    if (getenv("CRIM_NLM_DIRECT")) {   // the window-difference form (A/B and cross-check)
+        hipLaunchKernelGGL(k_nf_nlm<1>, grid, block, 0, s, sc.l0, sc.l1, H, W, sc.wl, prefix(wl), shift_l);
+        hipLaunchKernelGGL(k_nf_nlm<2>, grid, block, 0, s, sc.ab0, sc.ab1, H, W, sc.wab, prefix(wab), shift_ab);
+    } else {
+        const dim3 g2((W + NF2_TW - 1) / NF2_TW, (H + NF2_TH - 1) / NF2_TH, count);
+        hipLaunchKernelGGL(k_nf_nlm_corr<1>, g2, block, 0, s, sc.l0, sc.l1, H, W, sc.wl, prefix(wl), shift_l);
+        if (getenv("CRIM_NLM_CORR2")) {
+            hipLaunchKernelGGL(k_nf_nlm_corr<2>, g2, block, 0, s, sc.ab0, sc.ab1, H, W, sc.wab, prefix(wab), shift_ab);
+        } else {
+            const char* eb = getenv("CRIM_NLM_BLK");     // output rows per thread (experiments)
+            const int blk = eb ? atoi(eb) : 4;
+            const dim3 g3((W + NF3_TW - 1) / NF3_TW, (H + 4 * blk - 1) / (4 * blk), count);
+            if (blk == 2) hipLaunchKernelGGL(k_nf_nlm_rows<2>, g3, block, 0, s, sc.ab0, sc.ab1, H, W, sc.wab, prefix(wab), shift_ab);
+            else if (blk == 3) hipLaunchKernelGGL(k_nf_nlm_rows<3>, g3, block, 0, s, sc.ab0, sc.ab1, H, W, sc.wab, prefix(wab), shift_ab);
+            else hipLaunchKernelGGL(k_nf_nlm_rows<4>, g3, block, 0, s, sc.ab0, sc.ab1, H, W, sc.wab, prefix(wab), shift_ab);
+        }
+    }
     hipLaunchKernelGGL(k_nf_lab2bgr_sharpen, grid, block, 0, s, sc.l1, sc.ab1, d_out, H, W, apply_sharpening ? 1 : 0, t);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(s);

@@ -202,6 +202,284 @@ __global__ __launch_bounds__(256) void k_nf_nlm(const uint8_t* __restrict__ src,
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same non-local means in correlation form (the default): with T the pixel's window and W a
+// candidate's,  sum (T - W)^2 = sum T^2 + sum W^2 - 2 sum T W  -- exact in integers -- where
+//   * sum W^2 over a 9 x 9 window is one look-up in a box-filtered image of squares, built once per tile
+//     (and sum T^2 is the same image at the pixel itself);
+//   * sum T W is a dot product of BYTES: v_dot4_u32_u8 takes four pixels per instruction, 27 per window and
+//     channel instead of 81 subtract / multiply-add pairs.
+// Byte operands must line up: a window starts at any column, an LDS dword at a multiple of four.  The
+// pixel's own window is therefore kept in registers four times, shifted by 0..3 bytes inside three
+// dwords per row (zero elsewhere), and the lanes of a wave take the columns x = 4 lx + w (w = wave
+// index): the shift (w + dx) & 3 of a search step is then the same for the whole wave -- a compile-time
+// register choice once the walk along a search row is unrolled by four -- and the lanes' candidate
+// dwords are consecutive in LDS.  The three candidate dwords per row live in registers and move on by
+// one dword every fourth step.
+#define NF2_TW 128                         // tile: 128 columns (4 waves x 32 lanes, interleaved) ...
+#define NF2_TH 8                           // ... x 8 rows (2 per pass of a wave)
+#define NF2_RW (NF2_TW + 2 * NF_BORDER)    // 166: staged region
+#define NF2_RH (NF2_TH + 2 * NF_BORDER)    // 46
+#define NF2_PITCH 176                      // bytes per staged row (the last candidate dword ends at byte 167)
+#define NF2_BW (NF2_RW - NF_TW + 1)        // 158 window positions per row ...
+#define NF2_BH (NF2_RH - NF_TW + 1)        // ... and 38 rows of them
+#define NF2_BP 40                          // box-sum pitch: positions of one column class (x & 3) per row
+
+template <int CH>
+__global__ __launch_bounds__(256) void k_nf_nlm_corr(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int H, int W,
+                                                     const int* __restrict__ wtab, int nw, int shift) {
+    __shared__ __attribute__((aligned(16))) uint8_t sP[CH][NF2_RH][NF2_PITCH];   // the staged planes
+    // sum over channels of squares, 9 x 9 box sums: [column class x & 3][row][x >> 2]; rows up to NF2_RH
+    // during construction (horizontal sums first, vertical ones in place)
+    __shared__ uint32_t sB[4][NF2_RH][NF2_BP];
+    __shared__ int s_w[NF_WLDS];
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lx = lane & 31, ly = lane >> 5;
+    const size_t HW = (size_t)H * W;
+    const uint8_t* img = src + (size_t)blockIdx.z * HW * CH;
+    const int x0 = blockIdx.x * NF2_TW - NF_BORDER, y0 = blockIdx.y * NF2_TH - NF_BORDER;
+    for (int e = tid; e < NF_WLDS; e += 256) s_w[e] = e < nw ? wtab[e] : 0;
+    for (int e = tid; e < NF2_RH * NF2_PITCH; e += 256) {
+        const int ry = e / NF2_PITCH, rx = e - ry * NF2_PITCH;
+        const size_t q = (size_t)nf_reflect101(y0 + ry, H) * W + nf_reflect101(x0 + imin(rx, NF2_RW - 1), W);
+#pragma unroll
+        for (int c = 0; c < CH; ++c) sP[c][ry][rx] = rx < NF2_RW ? img[CH * q + c] : (uint8_t)0;
+    }
+    __syncthreads();
+    // horizontal 9-sums of the squares
+    for (int e = tid; e < NF2_RH * NF2_BW; e += 256) {
+        const int ry = e / NF2_BW, rx = e - ry * NF2_BW;
+        uint32_t acc = 0;
+#pragma unroll
+        for (int j = 0; j < NF_TW; ++j)
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const uint32_t v = sP[c][ry][rx + j];
+                acc += v * v;
+            }
+        sB[rx & 3][ry][rx >> 2] = acc;
+    }
+    __syncthreads();
+    // vertical 9-sums, in place: a thread owns a column and walks down it (row y only loses a value no
+    // later row needs)
+    if (tid < NF2_BW) {
+        uint32_t* col = &sB[tid & 3][0][tid >> 2];
+        uint32_t run = 0;
+#pragma unroll
+        for (int i = 0; i < NF_TW; ++i) run += col[i * NF2_BP];
+        for (int ry = 0; ry < NF2_BH; ++ry) {
+            const uint32_t top = col[ry * NF2_BP];
+            col[ry * NF2_BP] = run;
+            if (ry + 1 < NF2_BH) run += col[(ry + NF_TW) * NF2_BP] - top;
+        }
+    }
+    __syncthreads();
+
+    const int tx = 4 * lx + w;                    // this lane's column of the tile
+    for (int pass = 0; pass < NF2_TH / 2; ++pass) {
+        const int ty = 2 * pass + ly;             // ... and row
+        // the pixel's own window, shifted by s = 0..3 bytes inside three dwords per row
+        uint32_t T[CH][4][NF_TW][3];
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int r = 0; r < NF_TW; ++r) {
+                uint32_t b[NF_TW];
+#pragma unroll
+                for (int j = 0; j < NF_TW; ++j) b[j] = sP[c][ty + NF_SWH + r][tx + NF_SWH + j];
+#pragma unroll
+                for (int sft = 0; sft < 4; ++sft)
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        uint32_t v = 0;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int j = 4 * d + k - sft;
+                            if (j >= 0 && j < NF_TW) v |= b[j] << (8 * k);
+                        }
+                        T[c][sft][r][d] = v;
+                    }
+            }
+        const uint32_t sqT = sB[(tx + NF_SWH) & 3][ty + NF_SWH][(tx + NF_SWH) >> 2];
+        uint32_t est0 = 0, est1 = 0, wsum = 0;
+#pragma unroll 1
+        for (int dy = 0; dy < NF_SW; ++dy) {
+            // candidate dwords of the 9 window rows: region dwords lx + q .. lx + q + 2, q = (w + dx) >> 2
+            uint32_t Wd[CH][NF_TW][3];
+            const uint32_t* rowp[CH];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                rowp[c] = (const uint32_t*)&sP[c][ty + dy][0] + lx;
+#pragma unroll
+                for (int r = 0; r < NF_TW; ++r)
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) Wd[c][r][d] = rowp[c][r * (NF2_PITCH / 4) + d];
+            }
+            // u = w + dx runs over [w, w + 30]; unrolled by four so that the shift u & 3 is a constant
+#pragma unroll 1
+            for (int q = 0; q < (3 + NF_SW + 3) / 4; ++q) {
+#pragma unroll
+                for (int sft = 0; sft < 4; ++sft) {
+                    const int dx = 4 * q + sft - w;           // wave-uniform
+                    if (dx >= 0 && dx < NF_SW) {
+                        uint32_t acc3[3] = {0, 0, 0};   // three independent chains
+#pragma unroll
+                        for (int c = 0; c < CH; ++c)
+#pragma unroll
+                            for (int r = 0; r < NF_TW; ++r)
+#pragma unroll
+                                for (int d = 0; d < 3; ++d)
+                                    acc3[d] = __builtin_amdgcn_udot4(Wd[c][r][d], T[c][sft][r][d], acc3[d], false);
+                        const uint32_t acc = acc3[0] + acc3[1] + acc3[2];
+                        const int cx = tx + dx;               // window position: class (cx & 3) == sft, index lx + q
+                        const uint32_t sqW = sB[sft][ty + dy][lx + q];
+                        const int dist = (int)(sqT + sqW - 2u * acc);
+                        const int a = dist >> shift;
+                        const uint32_t wgt = (uint32_t)(a < NF_WLDS ? s_w[a] : (a < nw ? wtab[a] : 0));
+                        const int cy = ty + dy + NF_TWH;
+                        est0 += wgt * sP[0][cy][cx + NF_TWH];
+                        if (CH == 2) est1 += wgt * sP[CH - 1][cy][cx + NF_TWH];
+                        wsum += wgt;
+                    }
+                }
+                // the next four steps look one dword further right
+#pragma unroll
+                for (int c = 0; c < CH; ++c)
+#pragma unroll
+                    for (int r = 0; r < NF_TW; ++r) {
+                        Wd[c][r][0] = Wd[c][r][1];
+                        Wd[c][r][1] = Wd[c][r][2];
+                        Wd[c][r][2] = rowp[c][r * (NF2_PITCH / 4) + q + 3];
+                    }
+            }
+        }
+        const int ox = blockIdx.x * NF2_TW + tx, oy = blockIdx.y * NF2_TH + ty;
+        if (ox < W && oy < H) {
+            uint8_t* out = dst + ((size_t)blockIdx.z * HW + (size_t)oy * W + ox) * CH;
+            const uint32_t v0 = (est0 + wsum / 2) / wsum;
+            out[0] = (uint8_t)(v0 > 255u ? 255u : v0);
+            if (CH == 2) {
+                const uint32_t v1 = (est1 + wsum / 2) / wsum;
+                out[1] = (uint8_t)(v1 > 255u ? 255u : v1);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The window-difference form for the two-channel (a, b) image with BLK vertically adjacent output pixels
+// per thread: their windows at one search offset share all but one row each, so the per-row sums of
+// squared differences R_i (BLK + 8 rows of 9 dwords) are computed once and the BLK distances are sliding
+// sums of nine of them: (BLK + 8) * 9 / BLK difference pairs per pixel and candidate instead of 81.  (In
+// the correlation form nothing is shared between neighbouring pixels: their own windows differ.)  A wave
+// takes 64 consecutive columns (LDS reads of a row are consecutive dwords), wave w the rows BLK w ..
+#define NF3_TW 64
+template <int BLK>
+__global__ __launch_bounds__(256) void k_nf_nlm_rows(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int H, int W,
+                                                     const int* __restrict__ wtab, int nw, int shift) {
+    constexpr int TH = 4 * BLK;                       // tile rows
+    constexpr int RH = TH + 2 * NF_BORDER, RW = NF3_TW + 2 * NF_BORDER;
+    constexpr int PITCH = RW + 2;                     // dwords
+    constexpr int NR = BLK + NF_TW - 1;               // window rows a thread works on
+    __shared__ uint32_t sV[RH * PITCH];               // lane 0 = a, lane 1 = b of one pixel
+    __shared__ int s_w[NF_WLDS];
+    const int tid = threadIdx.x, tx = tid & 63, ty = (tid >> 6) * BLK;
+    const size_t HW = (size_t)H * W;
+    const uint8_t* img = src + (size_t)blockIdx.z * HW * 2;
+    const int x0 = blockIdx.x * NF3_TW - NF_BORDER, y0 = blockIdx.y * TH - NF_BORDER;
+    for (int e = tid; e < NF_WLDS; e += 256) s_w[e] = e < nw ? wtab[e] : 0;
+    for (int e = tid; e < RH * RW; e += 256) {
+        const int ry = e / RW, rx = e - ry * RW;
+        const size_t q = (size_t)nf_reflect101(y0 + ry, H) * W + nf_reflect101(x0 + rx, W);
+        sV[ry * PITCH + rx] = (uint32_t)img[2 * q] | ((uint32_t)img[2 * q + 1] << 16);
+    }
+    __syncthreads();
+    nf_v2s T[NR][NF_TW];
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int j = 0; j < NF_TW; ++j) T[r][j] = nf_as_v2s(sV[(ty + NF_SWH + r) * PITCH + tx + NF_SWH + j]);
+    uint32_t est0[BLK], est1[BLK], wsum[BLK];
+#pragma unroll
+    for (int o = 0; o < BLK; ++o) { est0[o] = 0; est1[o] = 0; wsum[o] = 0; }
+    // distances from here on have weight zero (the table's non-zero prefix is nw entries of 2^shift each)
+    const int zero_from = nw < (0x7fffffff >> shift) ? (nw << shift) : 0x7fffffff;
+    nf_v2s Wn[NR][NF_TW];   // candidate rows: column slot (j + dx) % 9 holds window column j at step dx (see k_nf_nlm)
+#pragma unroll 1
+    for (int dy = 0; dy < NF_SW; ++dy) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int j = 0; j < NF_TW; ++j) Wn[r][j] = nf_as_v2s(sV[(ty + dy + r) * PITCH + tx + j]);
+#pragma unroll 1
+        for (int dx0 = 0; dx0 < NF_SW; dx0 += NF_TW) {
+#pragma unroll
+            for (int k = 0; k < NF_TW; ++k) {
+                const int dx = dx0 + k;
+                if (dx < NF_SW) {
+                    int R[NR];
+                    auto row_sum = [&](int r) {
+                        int acc = 0;
+#pragma unroll
+                        for (int j = 0; j < NF_TW; ++j) {
+                            const nf_v2s d = T[r][j] - Wn[r][(j + k) % NF_TW];
+                            acc = __builtin_amdgcn_sdot2(d, d, acc, false);
+                        }
+                        R[r] = acc;
+                    };
+                    // Rows BLK-1 .. 8 belong to the windows of ALL of the thread's pixels: once their sum has
+                    // reached the distance beyond which every weight is zero -- in every lane -- the candidate
+                    // cannot contribute anywhere in the wave and the rest of its work is skipped (exact: only
+                    // additions of zero are left out).  Most candidates of the chroma image end here after two rows.
+                    int common = 0;
+                    bool dead = false;
+#pragma unroll
+                    for (int r = BLK - 1; r < NF_TW; ++r) {
+                        row_sum(r);
+                        common += R[r];
+                        if (r == BLK || r == NF_TW - 1) {
+                            if (__all(common >= zero_from)) { dead = true; break; }
+                        }
+                    }
+                    if (!dead) {
+#pragma unroll
+                        for (int r = 0; r < BLK - 1; ++r) row_sum(r);
+#pragma unroll
+                        for (int r = NF_TW; r < NR; ++r) row_sum(r);
+                        int dist = common;
+#pragma unroll
+                        for (int r = 0; r < BLK - 1; ++r) dist += R[r];
+#pragma unroll
+                        for (int o = 0; o < BLK; ++o) {
+                            if (o > 0) dist += R[o + NF_TW - 1] - R[o - 1];
+                            const int a = dist >> shift;
+                            const uint32_t wgt = (uint32_t)(a < NF_WLDS ? s_w[a] : (a < nw ? wtab[a] : 0));
+                            const uint32_t v = sV[(ty + o + dy + NF_TWH) * PITCH + tx + dx + NF_TWH];
+                            est0[o] += wgt * (v & 0xffffu);
+                            est1[o] += wgt * (v >> 16);
+                            wsum[o] += wgt;
+                        }
+                    }
+                    if (dx + 1 < NF_SW) {
+#pragma unroll
+                        for (int r = 0; r < NR; ++r) Wn[r][k] = nf_as_v2s(sV[(ty + dy + r) * PITCH + tx + dx + NF_TW]);
+                    }
+                }
+            }
+        }
+    }
+    const int ox = blockIdx.x * NF3_TW + tx;
+#pragma unroll
+    for (int o = 0; o < BLK; ++o) {
+        const int oy = blockIdx.y * TH + ty + o;
+        if (ox < W && oy < H) {
+            uint8_t* out = dst + ((size_t)blockIdx.z * HW + (size_t)oy * W + ox) * 2;
+            const uint32_t v0 = (est0[o] + wsum[o] / 2) / wsum[o], v1 = (est1[o] + wsum[o] / 2) / wsum[o];
+            out[0] = (uint8_t)(v0 > 255u ? 255u : v0);
+            out[1] = (uint8_t)(v1 > 255u ? 255u : v1);
+        }
+    }
+}
+
 // OpenCV's integer Lab -> linear BGR (COLOR_Lab2LBGR, 8 bit).
 __device__ __forceinline__ int nf_ab_to_xz(int v) {
     // C integer arithmetic: divisions truncate toward zero
