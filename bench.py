@@ -565,7 +565,10 @@ def main():
             shutil.rmtree(split_dir, ignore_errors=True)
         os.makedirs(split_dir, exist_ok=True)
         dev = int(os.environ.get("BENCH_DEVICE", local_rank))
-        split_proc = sw.launch_worker(rank, world, dev, split_dir, size=4096, patch=9, iters=args.split_iters, wait=600.0)
+        # (the one-GPU rehearsal of a multi-rank launch -- BENCH_BACKEND=gloo -- exchanges through host memory:
+        # RCCL refuses two ranks on one device)
+        split_proc = sw.launch_worker(rank, world, dev, split_dir, size=4096, patch=9, iters=args.split_iters, wait=600.0,
+                                      transport="host" if os.environ.get("BENCH_BACKEND") == "gloo" else "rccl")
     try:
         run_benchmark(args, rank, local_rank, world, distributed, want, B, split_proc, split_dir, profiled)
     finally:

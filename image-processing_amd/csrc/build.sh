@@ -10,3 +10,5 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
     -Wall -Wno-unused-result $EXTRA_HIPCC_FLAGS \
     -o "$OUT/libcriminisi_hip.so" "$HERE/crim_engine.hip"
 echo "built $OUT/libcriminisi_hip.so"
+# the hand-counted wait of the search kernels' select prologue is checked against the generated code
+python3 "$HERE/../../tools/check_select_prologue.py" "$OUT/libcriminisi_hip.so"

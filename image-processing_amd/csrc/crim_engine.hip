@@ -500,13 +500,12 @@ static void init_geometry(Params& p, int batch, int H, int W, int patch_size, un
     if (search_tiles > 4096) p.fused = 0;
     if (const char* e = getenv("CRIM_FUSED")) p.fused = (search_selects(p) && atoi(e)) ? 1 : 0;
     if (p.fused) {
-        // far waves per image: as many as the tile list may need, but the launch should be resident at
-        // once (k_step runs three blocks of four waves per CU; 9 blocks of an image are its near tiles,
-        // one its bookkeeping): measured on 50 images per launch, 14-15 blocks per image 39 us per
-        // iteration, 16 blocks 43.5 us
-        const int resident_blocks = 3 * 256;
-        int far_blocks = resident_blocks / lane_batch - 1 - CRIM_NEAR_TILES;
-        far_blocks = std::max(2, std::min(far_blocks, (1024 - CRIM_NEAR_TILES - 3) / 4));
+        // far waves per image: as many as the tile list may need (every wave then has at most one tile), at
+        // least 28, at most what the selecting search reads in one batch of loads; for batches about 1024
+        // blocks per launch (most near blocks leave at once).  Measured on 50 images per launch: 20 far waves
+        // 39.5 us per lock-step iteration, 28 to 60 waves 39.0-39.1 us, 12 waves 43 us.
+        int far_blocks = 1024 / lane_batch - 1 - CRIM_NEAR_TILES;
+        far_blocks = std::max(7, std::min(far_blocks, (1024 - CRIM_NEAR_TILES - 3) / 4));
         far_blocks = std::min(far_blocks, (p.tnx * p.tny + 3) / 4);
         p.nfar = 4 * far_blocks;
         if (getenv("CRIM_PGRID")) p.nfar = std::max(4, std::min(p.pgrid, 1024 - CRIM_NEAR_TILES - 3) / 4 * 4);

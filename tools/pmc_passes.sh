@@ -14,11 +14,11 @@ run valu SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VAL
 run lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_UNALIGNED_STALL SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_ACTIVE_INST_ANY || exit 1
 run fetch FETCH_SIZE || exit 1
 run write WRITE_SIZE || exit 1
-run grbm GRBM_GUI_ACTIVE GRBM_COUNT || exit 1
+# (a GRBM pass over the whole bench ran into its time limit on some boxes and is left out; tools/pmc_solo.sh has one)
 python3 - <<PY
 import csv, glob, collections, json
 summary = {}
-for name in ("valu", "lds", "fetch", "write", "grbm"):
+for name in ("valu", "lds", "fetch", "write"):
     files = glob.glob("$R/gpurun_out/pmc_%s/*/*counter_collection.csv" % name)
     if not files:
         print(name, "no counter file"); continue

@@ -1,6 +1,7 @@
 #!/bin/bash
 # PMC passes over the solo run (one lane, every launch alone on the GPU, all images live for the first
-# iterations): per-kernel counter averages.  Usage: tools/pmc_solo.sh "<solo_profile.py args>"
+# iterations): per-kernel counter averages, printed and kept as gpurun_out/pmc_solo_summary.txt.
+# Usage: tools/pmc_solo.sh "<solo_profile.py args>"
 R=$GRAFT_REPO_ROOT
 ARGS=${1:-"4096 60"}
 cd /tmp && export TMPDIR=/tmp
@@ -12,8 +13,9 @@ run() {
 run valu SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY || exit 1
 run lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES || exit 1
 run grbm GRBM_GUI_ACTIVE || exit 1
-python3 - <<PY
+python3 - <<PY | tee $R/gpurun_out/pmc_solo_summary.txt
 import csv, glob, collections
+print("solo_profile.py $ARGS: every launch alone on the GPU; per-launch averages of each counter")
 for name in ("valu", "lds", "grbm"):
     files = glob.glob("/tmp/pmcs_%s/*/*counter_collection.csv" % name)
     if not files:
