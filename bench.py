@@ -754,8 +754,9 @@ def run_benchmark(args, rank, local_rank, world, distributed, want, B, split_pro
             cfgs["configs[3] patch 15"] = config_large(capi, local_rank, 2048, 15, 3)
         if 4 in want:
             cfgs["configs[4]"] = config_large(capi, local_rank, 4096, 9, 4)
-            cfgs["configs[4]"]["multi_gpu_note"] = ("one GPU; the intra-image split over N GPUs (RCCL all-gather of 16 B "
-                                                    "per rank per iteration) is measured by `bench.py --gpus N`")
+            cfgs["configs[4]"]["multi_gpu_note"] = ("one GPU; the intra-image split over N GPUs (one in-place RCCL all-gather of the "
+                                                    "ranks' search-slot shares per iteration, 32 KB in all at this size) is "
+                                                    "measured by `bench.py --gpus N`")
         if 0 in want and not profiled:
             torch.cuda.synchronize()
             torch.cuda.empty_cache()
