@@ -1910,6 +1910,15 @@ __device__ __forceinline__ void publish_barrier() {
     __builtin_amdgcn_s_barrier();
 }
 
+#ifndef MSP_E2
+#define MSP_E2 1
+#endif
+#ifndef MSP_KEEP_BC
+#define MSP_KEEP_BC 0   // (measured: the 12 registers spill at four waves per SIMD, 222 against 187 us per launch)
+#endif
+#ifndef MSP_E2_DEPTH
+#define MSP_E2_DEPTH 3
+#endif
 #ifndef MSP_WPE
 #define MSP_WPE(P, CHROMA) (((P) > 9 || ((CHROMA) && (P) > 7)) ? 3 : 4)
 #endif
@@ -1929,7 +1938,17 @@ void k_search_pipe(Params p) {
     constexpr int NS = (P + 1) / 2;
     constexpr int R = MS_R;
     constexpr int NF = R + 2 * NS - 2;
-    constexpr int LROWS = MS_ROWS + 2 * NS - 1;
+    // E2: the 8 x 2 embedding (patch edges up to 9).  A matrix instruction's 16 columns are 8 x-shifts x
+    // 2 y-shifts of a window origin, its 16 rows are image positions 8 bytes apart, and its K = 64 slots are
+    // a 4-row x 16-column block of the image: the 16 columns hold 8 shifts + 9 taps - 1 exactly, and NI = 3
+    // such blocks hold 2 shifts + 9 taps - 1 = 10 of their 12 rows.  One instruction triple scores 256 windows
+    // (128 x-origins x 2 rows) with 192 multiply-adds per window and plane; the Toeplitz embedding of the
+    // larger patches (one row pair per instruction, 16 x-shifts + taps in 32 columns) needs 64 NS = 320.
+    constexpr bool E2 = MSP_E2 && P <= 9;
+    constexpr int NI = (P + 4) / 4;             // E2: row blocks per window pair ((P + 1) / 4, rounded up)
+    constexpr int NFR = 2 * NI + 2;             // E2: image row blocks (2 rows apart) a wave's 8 origin rows touch
+    constexpr int ZR = E2 ? 4 * NI + 1 : 2 * NS;   // template rows kept in LDS (E2: rows -1 .. 4 NI - 1)
+    constexpr int LROWS = E2 ? MS_ROWS + P - 1 : MS_ROWS + 2 * NS - 1;
     constexpr int C16 = MS_PITCH / 16;
     constexpr int POISON = 1 << 20;
     constexpr int NCH = LROWS * C16;            // 16-byte chunks of a plane tile
@@ -1942,7 +1961,7 @@ void k_search_pipe(Params p) {
     __shared__ __attribute__((aligned(16))) uint8_t ring[3][MSP_SLOT_BYTES];
     __shared__ __attribute__((aligned(16))) uint8_t dump[1024];   // lands the all-padding loads
     __shared__ __attribute__((aligned(16))) unsigned long long vbits[MS_ROWS * 4];
-    __shared__ __attribute__((aligned(16))) uint8_t zl[NCC + 1][2 * NS][48];
+    __shared__ __attribute__((aligned(16))) uint8_t zl[NCC + 1][ZR][48];
     __shared__ double s_c[4];
     __shared__ unsigned s_i[4];
     __shared__ int s_bound;
@@ -2055,6 +2074,12 @@ void k_search_pipe(Params p) {
     const uint8_t* inv = p.invalid + (size_t)b * H * p.Wi;
     const uint8_t* mask = p.mask + b * HW;
     const int wx = x0 + 64 * (lane >> 4) + (lane & 15);
+    // Which window accumulator a, element j of this lane holds.  Toeplitz embedding: origin row a of the wave,
+    // x = wx + 16 j.  E2: a = 2 Y + xg, origin row 2 Y + bit 3 of the lane, x = x0 + 128 xg + 32 (lane / 16) +
+    // 8 j + (lane & 7).
+    const int e2y = (lane >> 3) & 1, e2x = x0 + 32 * (lane >> 4) + (lane & 7);
+    auto win_row = [&](int a) { return E2 ? 2 * (a >> 1) + e2y : a; };
+    auto win_x = [&](int a, int j) { return E2 ? e2x + 128 * (a & 1) + 8 * j : wx + 16 * j; };
 
     // ---- ring loads.  Chunk c = tid + 256 k of a tile is row c / C16, bytes 16 (c % C16) ..;
     // columns beyond the plane are read from a clamped address: only windows that are
@@ -2119,13 +2144,13 @@ void k_search_pipe(Params p) {
         constexpr int BEHIND = 3 * NK + 1;
         asm volatile("s_waitcnt vmcnt(%4)" : "+v"(sel_em), "+v"(sel_e0), "+v"(sel_e1), "+v"(sel_e2) : "n"(BEHIND) : "memory");
     }
-    constexpr int NZ = (NCC + 1) * 2 * NS;
+    constexpr int NZ = (NCC + 1) * ZR;
     static_assert(NZ <= 256, "one template row per thread");
     if constexpr (!SELECT) {
         if (tid < NZ) {
-            const int row = tid % (2 * NS), type = tid / (2 * NS);
+            const int row = tid % ZR - (E2 ? 1 : 0), type = tid / ZR;
             uint4 zv = make_uint4(0, 0, 0, 0);
-            if (row < P && (type == NCC || ((chmask >> type) & 1)))
+            if (row >= 0 && row < P && (type == NCC || ((chmask >> type) & 1)))
                 zv = *(const uint4*)d->zrows[type == NCC ? 3 : type][row];
             uint4* z = (uint4*)&zl[0][0][0] + 3 * tid;
             z[0] = make_uint4(0, 0, 0, 0); z[1] = zv; z[2] = make_uint4(0, 0, 0, 0);
@@ -2173,9 +2198,9 @@ void k_search_pipe(Params p) {
             (p.desc + b)->t_select = (long long)wall_clock64();
         }
         if (tid < NZ) {
-            const int row = tid % (2 * NS), type = tid / (2 * NS);
+            const int row = tid % ZR - (E2 ? 1 : 0), type = tid / ZR;
             unsigned long long lo = 0, hi = 0;
-            if (row < P && (type == NCC || ((chmask >> type) & 1))) {
+            if (row >= 0 && row < P && (type == NCC || ((chmask >> type) & 1))) {
                 const uint8_t* src = type == NCC ? &s_sk[row * P] : (const uint8_t*)&s_st[type][row * P];
 #pragma unroll
                 for (int c = 0; c < P; ++c) {
@@ -2193,27 +2218,90 @@ void k_search_pipe(Params p) {
 
     STAMP_MID(34);
     const int g = lane >> 4;
-    const int aoff = (wv * R + (g >> 1)) * MS_PITCH + 16 * ((lane & 15) + (g & 1));
-    const int zoff = (g >> 1) * 48 + 16 + 16 * (g & 1) - (lane & 15);
+    // E2: K-group g of a matrix instruction holds rows 2 (g / 2), 2 (g / 2) + 1 of the 4-row block and its
+    // columns 8 (g & 1) .. + 7: the lanes of groups 0 and 1 (2 and 3) then read the same rows 8 bytes apart,
+    // lane (m, 1) the very quadword of lane (m + 1, 0), so a half wave's 64-bit reads touch every bank once.
+    const int aoff = E2 ? (wv * R + 2 * (g >> 1)) * MS_PITCH + 8 * ((lane & 15) + (g & 1))
+                        : (wv * R + (g >> 1)) * MS_PITCH + 16 * ((lane & 15) + (g & 1));
+    // E2: the last row block of the last wave ends below the staged rows; its lower half only meets template
+    // rows beyond the patch (all zero), so those lanes read two rows higher instead
+    constexpr bool E2_LAST_CLAMPED = E2 && (MS_ROWS - R + 2 * (NFR - 1) + 3 >= LROWS);
+    const int aoff_last = (E2_LAST_CLAMPED && g >= 2) ? aoff - 2 * MS_PITCH : aoff;
+    const int zoff = E2 ? (2 * (g >> 1) - e2y + 1) * 48 + 16 + 8 * (g & 1) - (lane & 7)
+                        : (g >> 1) * 48 + 16 + 16 * (g & 1) - (lane & 15);
     auto fragments = [&](int type, v4i* Bf) {
         const uint8_t* zb = &zl[type][0][0] + (zoff & ~3);
         const int sh = zoff & 3;
+        if constexpr (E2) {
+            // row block i, rows 4 i + 2 (g / 2) + {0, 1} - (y-shift) of the template, 8 columns from
+            // 8 (g & 1) - (x-shift): two unaligned 8-byte windows of the zero-padded rows
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const uint32_t* q = (const uint32_t*)(zb + s * 96);
-            const uint32_t w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3], w4 = q[4];
-            Bf[s][0] = (int)__builtin_amdgcn_alignbyte(w1, w0, sh);
-            Bf[s][1] = (int)__builtin_amdgcn_alignbyte(w2, w1, sh);
-            Bf[s][2] = (int)__builtin_amdgcn_alignbyte(w3, w2, sh);
-            Bf[s][3] = (int)__builtin_amdgcn_alignbyte(w4, w3, sh);
+            for (int i = 0; i < NI; ++i) {
+                const uint32_t* q0 = (const uint32_t*)(zb + (4 * i) * 48);
+                const uint32_t* q1 = (const uint32_t*)(zb + (4 * i + 1) * 48);
+                const uint32_t a0 = q0[0], a1 = q0[1], a2 = q0[2];
+                const uint32_t b0 = q1[0], b1 = q1[1], b2 = q1[2];
+                Bf[i][0] = (int)__builtin_amdgcn_alignbyte(a1, a0, sh);
+                Bf[i][1] = (int)__builtin_amdgcn_alignbyte(a2, a1, sh);
+                Bf[i][2] = (int)__builtin_amdgcn_alignbyte(b1, b0, sh);
+                Bf[i][3] = (int)__builtin_amdgcn_alignbyte(b2, b1, sh);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const uint32_t* q = (const uint32_t*)(zb + s * 96);
+                const uint32_t w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3], w4 = q[4];
+                Bf[s][0] = (int)__builtin_amdgcn_alignbyte(w1, w0, sh);
+                Bf[s][1] = (int)__builtin_amdgcn_alignbyte(w2, w1, sh);
+                Bf[s][2] = (int)__builtin_amdgcn_alignbyte(w3, w2, sh);
+                Bf[s][3] = (int)__builtin_amdgcn_alignbyte(w4, w3, sh);
+            }
         }
     };
-    v4i Bk[NS];
+    constexpr int NB = E2 ? NI : NS;            // template fragments per plane kind
+    v4i Bk[NB];
+    // grey engines with the 8 x 2 embedding keep the one cross-term channel's fragments as well
+    constexpr bool KEEP_BC = MSP_KEEP_BC && E2 && !CHROMA;
+    v4i Bc0[KEEP_BC ? NB : 1];
     v4i acc[R];
-    // Two row registers, refilled alternately: the read of row r + 2 is issued right after the matrix
-    // instructions of row r, so its LDS latency passes under those of row r + 1 (left to itself hipcc
-    // reads rows in pairs and waits for each pair with nothing in flight).
+    // Toeplitz embedding: two row registers, refilled alternately: the read of row r + 2 is issued right after
+    // the matrix instructions of row r, so its LDS latency passes under those of row r + 1 (left to itself
+    // hipcc reads rows in pairs and waits for each pair with nothing in flight).
+    // E2: image fragment (f, xg) = rows 2 f .. 2 f + 3 of the wave's rows, columns 128 xg ..; it serves the
+    // window pairs Y with row block i = (f - Y) / 2.  MSP_E2_DEPTH fragment registers, all but one being read.
     auto plane_pass = [&](int slot, const v4i* Bf) {
+        if constexpr (E2) {
+            const uint8_t* base = &ring[slot][0];
+            auto read = [&](int k) {
+                const int f = k >> 1, xg = k & 1;
+                const int off = (E2_LAST_CLAMPED && f == NFR - 1) ? aoff_last : aoff;
+                const unsigned long long* q = (const unsigned long long*)(base + off + f * 2 * MS_PITCH + 128 * xg);
+                const unsigned long long lo = q[0], hi = q[MS_PITCH / 8];
+                return v4i{(int)(uint32_t)lo, (int)(uint32_t)(lo >> 32), (int)(uint32_t)hi, (int)(uint32_t)(hi >> 32)};
+            };
+            auto use = [&](int k, const v4i& F) {
+                const int f = k >> 1, xg = k & 1;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int Y = f - 2 * i;
+                    if (Y >= 0 && Y < R / 2)
+                        acc[2 * Y + xg] = __builtin_amdgcn_mfma_i32_16x16x64_i8(F, Bf[i], acc[2 * Y + xg], 0, 0, 0);
+                }
+            };
+            constexpr int NK2 = 2 * NFR;
+            constexpr int D = MSP_E2_DEPTH;     // fragment registers: D - 1 reads in flight
+            v4i F[D];
+#pragma unroll
+            for (int k = 0; k < D - 1; ++k) F[k] = read(k);
+#pragma unroll
+            for (int k = 0; k < NK2; ++k) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (k + D - 1 < NK2) F[(k + D - 1) % D] = read(k + D - 1);
+                __builtin_amdgcn_sched_barrier(0);
+                use(k, F[k % D]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
         const uint8_t* base = &ring[slot][0] + aoff;
         static_assert(NF % 2 == 0, "rows are consumed in pairs");
         v4i Fa = *(const v4i*)(base), Fb = *(const v4i*)(base + MS_PITCH);
@@ -2221,6 +2309,9 @@ void k_search_pipe(Params p) {
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const int yy = r - 2 * s;
+#ifdef TIMING_MFMA_STEPS
+                if (s >= TIMING_MFMA_STEPS) continue;   // timing build: wrong sums, fewer matrix instructions
+#endif
                 if (yy >= 0 && yy < R)
                     acc[yy] = __builtin_amdgcn_mfma_i32_16x16x64_i8(F, Bf[s], acc[yy], 0, 0, 0);
             }
@@ -2237,6 +2328,7 @@ void k_search_pipe(Params p) {
             if (r + 3 < NF) Fb = *(const v4i*)(base + (r + 3) * MS_PITCH);
         }
         __builtin_amdgcn_sched_barrier(0);
+        }
     };
     // the block's lowest cost of a tile is written by thread 0 one barrier after the waves posted theirs
     auto store_result = [&](int tb) {
@@ -2307,7 +2399,10 @@ void k_search_pipe(Params p) {
             if (j == 0) {
                 if (t == 0) STAMP_MID(35);
                 if (t > 0 && tid == 0) store_result(tb - 1);
-                if (t == 0) fragments(NCC, Bk);
+                if (t == 0) {
+                    fragments(NCC, Bk);
+                    if constexpr (KEEP_BC) fragments(0, Bc0);
+                }
                 // every wave looks at the whole tile's validity words: is there any admissible window?
                 const uint4 q = ((const uint4*)vb)[lane];
                 const bool tile_any = clipped || __ballot((q.x & q.y & q.z & q.w) != 0xffffffffu) != 0;
@@ -2334,19 +2429,29 @@ void k_search_pipe(Params p) {
                     } else {
 #pragma unroll
                         for (int yy = 0; yy < R; ++yy) {
-                            const unsigned long long w = vb[(wv * R + yy) * 4 + g] >> (lane & 15);
-                            const uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
-                            acc[yy][0] = sbit_field(lo, 0) << 20;
-                            acc[yy][1] = sbit_field(lo, 16) << 20;
-                            acc[yy][2] = sbit_field(hi, 0) << 20;
-                            acc[yy][3] = sbit_field(hi, 16) << 20;
+                            if constexpr (E2) {
+                                // windows 32 (g & 1) + 8 j + (lane & 7) of word 2 xg + g / 2
+                                const unsigned long long w = vb[(wv * R + win_row(yy)) * 4 + 2 * (yy & 1) + (g >> 1)];
+                                const uint32_t lo = ((g & 1) ? (uint32_t)(w >> 32) : (uint32_t)w) >> (lane & 7);
+                                acc[yy][0] = sbit_field(lo, 0) << 20;
+                                acc[yy][1] = sbit_field(lo, 8) << 20;
+                                acc[yy][2] = sbit_field(lo, 16) << 20;
+                                acc[yy][3] = sbit_field(lo, 24) << 20;
+                            } else {
+                                const unsigned long long w = vb[(wv * R + yy) * 4 + g] >> (lane & 15);
+                                const uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
+                                acc[yy][0] = sbit_field(lo, 0) << 20;
+                                acc[yy][1] = sbit_field(lo, 16) << 20;
+                                acc[yy][2] = sbit_field(hi, 0) << 20;
+                                acc[yy][3] = sbit_field(hi, 16) << 20;
+                            }
                         }
                     }
                 } else {
                     int anyvalid = 0;
                     for (int yy = 0; yy < R; ++yy)
                         for (int jj = 0; jj < 4; ++jj) {
-                            const int y = wy + yy, x = wx + 16 * jj;
+                            const int y = wy + win_row(yy), x = win_x(yy, jj);
                             bool wok;
                             if constexpr (SELECT) wok = window_valid_geom(p, 1, s_red[1 + 3], s_red[2 + 3], inv, mask, y, x);
                             else wok = window_valid(p, d, inv, mask, y, x);
@@ -2370,19 +2475,31 @@ void k_search_pipe(Params p) {
             if (j == 0 || j == NP - 1) {
                 if (wave_on) plane_pass(slot_of(j), Bk);
             } else if (wave_on && ((chmask >> (j - 1)) & 1)) {
-                // the cross-term fragments are rebuilt for every tile: keeping them would cost 20
-                // registers per channel and the fourth wave per SIMD
-                v4i Bc[NS];
-                fragments(j - 1, Bc);
-                plane_pass(slot_of(j), Bc);
+                if constexpr (KEEP_BC) {
+                    plane_pass(slot_of(j), Bc0);
+                } else {
+                    // the cross-term fragments are rebuilt for every tile: keeping them would cost 20
+                    // registers per channel (12 with the 8 x 2 embedding) and the fourth wave per SIMD
+                    v4i Bc[NB];
+                    fragments(j - 1, Bc);
+                    plane_pass(slot_of(j), Bc);
+                }
             }
         }
 
         if (clean) {
             // windows beyond the right edge, as far below as a start value of -POISON would have put them
-            const int edge_add = wx + 48 >= ncx ? -(POISON << 8) : 0;
+            if constexpr (E2) {
+                // (only the tile's last 16 columns can lie beyond the edge: elements 2 and 3 of the right halves)
+                const int add2 = win_x(1, 2) >= ncx ? -(POISON << 8) : 0;
+                const int add3 = win_x(1, 3) >= ncx ? -(POISON << 8) : 0;
 #pragma unroll
-            for (int yy = 0; yy < R; ++yy) acc[yy][3] += edge_add;
+                for (int yy = 1; yy < R; yy += 2) { acc[yy][2] += add2; acc[yy][3] += add3; }
+            } else {
+                const int edge_add = wx + 48 >= ncx ? -(POISON << 8) : 0;
+#pragma unroll
+                for (int yy = 0; yy < R; ++yy) acc[yy][3] += edge_add;
+            }
         }
         if (t == 0) STAMP_MID(36);
         // pricing, as in k_search_mfma
@@ -2412,7 +2529,7 @@ void k_search_pipe(Params p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (acc[yy][j] >= thr) {
-                        const int y = wy + yy, x = wx + 16 * j;
+                        const int y = wy + win_row(yy), x = win_x(yy, j);
                         // cand_cost with the descriptor fields read up front
                         const double dy = ((double)y + ph_half) - ty;
                         const double dx = ((double)x + pw_half) - tx;
