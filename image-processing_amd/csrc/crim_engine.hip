@@ -1771,6 +1771,11 @@ int filter_noise_device(int count, int H, int W, const uint8_t* d_in, uint8_t* d
     if (getenv("CRIM_NLM_DIRECT")) {   // the window-difference form (A/B and cross-check)
         hipLaunchKernelGGL(k_nf_nlm<1>, grid, block, 0, s, sc.l0, sc.l1, H, W, sc.wl, prefix(wl), shift_l);
         hipLaunchKernelGGL(k_nf_nlm<2>, grid, block, 0, s, sc.ab0, sc.ab1, H, W, sc.wab, prefix(wab), shift_ab);
+    } else if (!getenv("CRIM_NLM_CORR") && prefix(wl) < NF_WLDS && prefix(wab) < NF_WLDS) {
+        // row products shared down a column (the default)
+        const dim3 gl((W + NF2_TW - 1) / NF2_TW, (H + 15) / 16, count), gab((W + NF2_TW - 1) / NF2_TW, (H + 7) / 8, count);
+        hipLaunchKernelGGL((k_nf_nlm_vs<1, 8>), gl, block, 0, s, sc.l0, sc.l1, H, W, sc.wl, prefix(wl), shift_l);
+        hipLaunchKernelGGL((k_nf_nlm_vs<2, 4>), gab, block, 0, s, sc.ab0, sc.ab1, H, W, sc.wab, prefix(wab), shift_ab);
     } else {
         const dim3 g2((W + NF2_TW - 1) / NF2_TW, (H + NF2_TH - 1) / NF2_TH, count);
         hipLaunchKernelGGL(k_nf_nlm_corr<1>, g2, block, 0, s, sc.l0, sc.l1, H, W, sc.wl, prefix(wl), shift_l);

@@ -480,6 +480,176 @@ __global__ __launch_bounds__(256) void k_nf_nlm_rows(const uint8_t* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Correlation form with the row products shared down a column (the default).  The product sum of two
+// windows is a sum of nine ROW products, and the row product of image row Y at column x with the row
+// dy below and dx to the right belongs to the windows of nine vertically adjacent pixels: a thread that
+// owns BLK consecutive pixels of one column computes BLK + 8 row products per candidate offset (three
+// v_dot4_u32_u8 each and channel) and slides a nine-row sum down them -- 3 (BLK + 8) / BLK byte dot
+// products per pixel, candidate and channel instead of 27.
+// Alignment as in k_nf_nlm_corr (lanes take the columns x = 4 lx + wave, so a candidate's byte offset
+// inside its dwords is the same for the whole wave), but the search offsets are walked by alignment
+// class: for one class the pixel's own rows are shifted once, the candidate dwords of a search row
+// slide on by one whole dword per step (eight steps, unrolled: no register moves), and the candidate's
+// centre pixel is always a byte of its middle dword.
+// Requires nw < NF_WLDS (the weight of a distance beyond the table's non-zero prefix is read from the
+// zero padding).
+#ifndef NF_VS_WPE
+#define NF_VS_WPE(CH) ((CH) == 1 ? 3 : 2)
+#endif
+template <int CH, int BLK>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NF_VS_WPE(CH), NF_VS_WPE(CH)))) void k_nf_nlm_vs(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int H, int W,
+                                                   const int* __restrict__ wtab, int nw, int shift) {
+    constexpr int TH = 2 * BLK;                        // tile rows: lanes 0..31 the upper BLK, 32..63 the lower
+    constexpr int RH = TH + 2 * NF_BORDER;             // staged rows
+    constexpr int BH = RH - NF_TW + 1;                 // rows of window positions
+    constexpr int NR = BLK + NF_TW - 1;                // image rows under a thread's windows
+    constexpr int PD = NF2_PITCH / 4;                  // staged row pitch in dwords
+    __shared__ __attribute__((aligned(16))) uint8_t sP[CH][RH][NF2_PITCH];
+    __shared__ uint32_t sB[4][RH][NF2_BP];             // box sums of squares, [column class][row][column / 4]
+    __shared__ int s_w[NF_WLDS];
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lx = lane & 31, ly = lane >> 5;
+    const size_t HW = (size_t)H * W;
+    const uint8_t* img = src + (size_t)blockIdx.z * HW * CH;
+    const int x0 = blockIdx.x * NF2_TW - NF_BORDER, y0 = blockIdx.y * TH - NF_BORDER;
+    for (int e = tid; e < NF_WLDS; e += 256) s_w[e] = e < nw ? wtab[e] : 0;
+    for (int e = tid; e < RH * NF2_PITCH; e += 256) {
+        const int ry = e / NF2_PITCH, rx = e - ry * NF2_PITCH;
+        const size_t q = (size_t)nf_reflect101(y0 + ry, H) * W + nf_reflect101(x0 + imin(rx, NF2_RW - 1), W);
+#pragma unroll
+        for (int c = 0; c < CH; ++c) sP[c][ry][rx] = rx < NF2_RW ? img[CH * q + c] : (uint8_t)0;
+    }
+    __syncthreads();
+    for (int e = tid; e < RH * NF2_BW; e += 256) {     // horizontal 9-sums of the squares
+        const int ry = e / NF2_BW, rx = e - ry * NF2_BW;
+        uint32_t acc = 0;
+#pragma unroll
+        for (int j = 0; j < NF_TW; ++j)
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const uint32_t v = sP[c][ry][rx + j];
+                acc += v * v;
+            }
+        sB[rx & 3][ry][rx >> 2] = acc;
+    }
+    __syncthreads();
+    if (tid < NF2_BW) {                                // vertical 9-sums in place, one column per thread
+        uint32_t* col = &sB[tid & 3][0][tid >> 2];
+        uint32_t run = 0;
+#pragma unroll
+        for (int i = 0; i < NF_TW; ++i) run += col[i * NF2_BP];
+        for (int ry = 0; ry < BH; ++ry) {
+            const uint32_t top = col[ry * NF2_BP];
+            col[ry * NF2_BP] = run;
+            if (ry + 1 < BH) run += col[(ry + NF_TW) * NF2_BP] - top;
+        }
+    }
+    __syncthreads();
+
+    const int tx = 4 * lx + w;                         // this thread's column of the tile
+    const int ty0 = ly * BLK;                          // ... and first row
+    uint32_t sqT[BLK], wsum[BLK], est[CH][BLK];
+#pragma unroll
+    for (int o = 0; o < BLK; ++o) {
+        sqT[o] = sB[(tx + NF_SWH) & 3][ty0 + o + NF_SWH][(tx + NF_SWH) >> 2];
+        wsum[o] = 0;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) est[c][o] = 0;
+    }
+    const int own_dw = lx + ((w + NF_SWH) >> 2);       // the own windows start at byte own_sh of this dword
+    const int own_sh = 8 * ((w + NF_SWH) & 3);         // (wave-uniform, in bits)
+#pragma unroll 1
+    for (int cls = 0; cls < 4; ++cls) {
+        // candidates whose first column is of class cls: dx = r4, r4 + 4, ...
+        const int r4 = (cls - w) & 3, qd = (w + r4) >> 2, cbits = 8 * cls;
+        // the own rows with their 9 bytes at bytes cls .. cls + 8 of three dwords, zero elsewhere
+        uint32_t Ts[CH][NR][3];
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const uint32_t* rp = (const uint32_t*)&sP[c][ty0 + NF_SWH + r][0] + own_dw;
+                const unsigned long long d01 = (unsigned long long)rp[0] | ((unsigned long long)rp[1] << 32);
+                const unsigned long long d12 = (unsigned long long)rp[1] | ((unsigned long long)rp[2] << 32);
+                const uint32_t c0 = (uint32_t)(d01 >> own_sh), c1 = (uint32_t)(d12 >> own_sh), c2 = (rp[2] >> own_sh) & 0xffu;
+                const unsigned long long lo = ((unsigned long long)c0 | ((unsigned long long)c1 << 32)) << cbits;
+                const unsigned long long hi = ((unsigned long long)c1 | ((unsigned long long)c2 << 32)) << cbits;
+                Ts[c][r][0] = (uint32_t)lo;
+                Ts[c][r][1] = (uint32_t)(lo >> 32);
+                Ts[c][r][2] = (uint32_t)(hi >> 32);
+            }
+#pragma unroll 1
+        for (int dy = 0; dy < NF_SW; ++dy) {
+            // candidate rows ty0 + dy + r; step k looks at dwords k .. k + 2 from here, kept in slots (k + d) % 3
+            const uint32_t* rowp[CH];
+            uint32_t Wd[CH][NR][3];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                rowp[c] = (const uint32_t*)&sP[c][ty0 + dy][0] + lx + qd;
+#pragma unroll
+                for (int r = 0; r < NR; ++r)
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) Wd[c][r][d] = rowp[c][r * PD + d];
+            }
+            const uint32_t* sbp = &sB[cls][ty0 + dy][lx + qd];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (r4 + 4 * k < NF_SW) {              // wave-uniform
+                    uint32_t RC[NR];
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) {
+                        uint32_t acc = 0;
+#pragma unroll
+                        for (int c = 0; c < CH; ++c)
+#pragma unroll
+                            for (int d = 0; d < 3; ++d)
+                                acc = __builtin_amdgcn_udot4(Wd[c][r][(k + d) % 3], Ts[c][r][d], acc, false);
+                        RC[r] = acc;
+                    }
+                    uint32_t run = 0;
+#pragma unroll
+                    for (int r = 0; r < NF_TW; ++r) run += RC[r];
+#pragma unroll
+                    for (int o = 0; o < BLK; ++o) {
+                        if (o > 0) run += RC[o + NF_TW - 1] - RC[o - 1];
+                        const uint32_t sqW = sbp[o * NF2_BP + k];
+                        const int dist = (int)(sqT[o] + sqW - 2u * run);
+                        const int a = imin(dist >> shift, NF_WLDS - 1);
+                        const uint32_t wgt = (uint32_t)s_w[a];
+                        // the candidate's centre pixel: byte cls of the middle dword of its row 4
+#pragma unroll
+                        for (int c = 0; c < CH; ++c)
+                            est[c][o] += wgt * ((Wd[c][o + NF_TWH][(k + 1) % 3] >> cbits) & 0xffu);
+                        wsum[o] += wgt;
+                    }
+                }
+                // (steps are kept apart: scheduled across one another they need twice the registers)
+                __builtin_amdgcn_sched_barrier(0);
+                if (k + 1 < 8) {
+#pragma unroll
+                    for (int c = 0; c < CH; ++c)
+#pragma unroll
+                        for (int r = 0; r < NR; ++r) Wd[c][r][k % 3] = rowp[c][r * PD + k + 3];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    const int ox = blockIdx.x * NF2_TW + tx;
+#pragma unroll
+    for (int o = 0; o < BLK; ++o) {
+        const int oy = blockIdx.y * TH + ty0 + o;
+        if (ox < W && oy < H) {
+            uint8_t* out = dst + ((size_t)blockIdx.z * HW + (size_t)oy * W + ox) * CH;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const uint32_t v = (est[c][o] + wsum[o] / 2) / wsum[o];
+                out[c] = (uint8_t)(v > 255u ? 255u : v);
+            }
+        }
+    }
+}
+
 // OpenCV's integer Lab -> linear BGR (COLOR_Lab2LBGR, 8 bit).
 __device__ __forceinline__ int nf_ab_to_xz(int v) {
     // C integer arithmetic: divisions truncate toward zero

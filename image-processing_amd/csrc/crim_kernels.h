@@ -1919,6 +1919,9 @@ __device__ __forceinline__ void publish_barrier() {
 #ifndef MSP_E2_DEPTH
 #define MSP_E2_DEPTH 3
 #endif
+#ifndef MSP_SEL_WPE
+#define MSP_SEL_WPE(P, CHROMA) 3
+#endif
 #ifndef MSP_WPE
 #define MSP_WPE(P, CHROMA) (((P) > 9 || ((CHROMA) && (P) > 7)) ? 3 : 4)
 #endif
@@ -1931,7 +1934,7 @@ __device__ __forceinline__ void publish_barrier() {
 // (SELECT instances serve small batches, which never fill four blocks per CU: three waves per SIMD
 // give them the registers the extra prologue needs)
 template <int P, bool CHROMA, bool SELECT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SELECT ? 3 : MSP_WPE(P, CHROMA), SELECT ? 3 : MSP_WPE(P, CHROMA))))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SELECT ? MSP_SEL_WPE(P, CHROMA) : MSP_WPE(P, CHROMA), SELECT ? MSP_SEL_WPE(P, CHROMA) : MSP_WPE(P, CHROMA))))
 void k_search_pipe(Params p) {
     constexpr int NCC = CHROMA ? 3 : 1;         // cross-term channels
     constexpr int NP = NCC + 2;                 // planes (passes) per tile
@@ -2086,7 +2089,11 @@ void k_search_pipe(Params p) {
     // inadmissible anyway see those bytes.  Rows below the image are read as they come (the next
     // plane's or image's rows; the buffer ends in spare rows for the last image).  The offsets
     // are the same for all planes of a tile and advance by 32 rows per tile.
+#ifdef TIMING_RESIDENT   // timing build: every block reads the planes of one of 64 images (cache-resident), wrong results
+    const uint8_t* pl = p.planes + (size_t)(b & 63) * CRIM_NPL * H * Wp;
+#else
     const uint8_t* pl = p.planes + (size_t)b * CRIM_NPL * H * Wp;
+#endif
     const size_t plane_bytes = (size_t)H * Wp;
     // plane consumed by pass k of a tile: h digits, L, [a, b,] l digits
     auto plane_of = [](int k) { return k == 0 ? 6 : (k == NP - 1 ? 5 : k - 1); };

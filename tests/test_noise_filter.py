@@ -140,3 +140,31 @@ def test_gpu_filter_noise_batch_and_engine_in_place():
         eng.filter_noise(median_ksize=3, nlm_h=7, apply_sharpening=True)
         out = eng.download()[0][0]
     assert np.array_equal(out, nf.filter_noise(c_oracle.run(imgs[1], m, 9)[0], 3, 7, True))
+
+
+@gpu
+@pytest.mark.parametrize("h", [7, 40])
+def test_gpu_nlm_kernel_generations_agree(monkeypatch, h):
+    """The three forms of the non-local means (window differences; byte correlation against box-filtered
+    squares; the same with row products shared down a column, the default) on an image of several tiles
+    with ragged edges: identical outputs, and equal to the restatement on a crop-sized image.  h = 40
+    makes the L weight table's non-zero prefix longer than the kernels' LDS copy (the default form then
+    hands over to the second one)."""
+    import crim_hip_capi as capi
+    img = crim_synth.xray_like(150, 301, 77, colour=True)
+    rng = np.random.default_rng(3)
+    img = np.clip(img.astype(np.int16) + rng.integers(-6, 7, img.shape), 0, 255).astype(np.uint8)
+    outs = {}
+    for name, env in (("shared_rows", {}), ("correlation", {"CRIM_NLM_CORR": "1"}), ("differences", {"CRIM_NLM_DIRECT": "1"})):
+        for k in ("CRIM_NLM_CORR", "CRIM_NLM_DIRECT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        outs[name] = capi.filter_noise(img, median_ksize=3, nlm_h=h, apply_sharpening=True)
+    assert np.array_equal(outs["shared_rows"], outs["correlation"])
+    assert np.array_equal(outs["shared_rows"], outs["differences"])
+    for k in ("CRIM_NLM_CORR", "CRIM_NLM_DIRECT"):
+        monkeypatch.delenv(k, raising=False)
+    small = np.ascontiguousarray(img[:40, :140])
+    assert np.array_equal(capi.filter_noise(small, median_ksize=3, nlm_h=h, apply_sharpening=True),
+                          nf.filter_noise(small, median_ksize=3, nlm_h=h, apply_sharpening=True))

@@ -28,7 +28,9 @@ for off in offs:
             cur[k] = v
         if k == "symbol":
             cur["symbol"] = v
-            rows.append(cur)
+        if k == "wavefront_size":      # the last key of a kernel's entry (keys are in alphabetical order)
+            if "symbol" in cur:
+                rows.append(cur)
             cur = {}
     for r in rows:
         sym = subprocess.run(["c++filt", r["symbol"].replace(".kd", "").strip("'")], capture_output=True, text=True).stdout.strip()

@@ -1,5 +1,5 @@
 """Time of the noise-filter stage on 100 synthetic 256x256 images (host arrays in and out).
-python3 tools/nlm_time.py   (CRIM_NLM_DIRECT=1: the window-difference kernels)"""
+python3 tools/nlm_time.py   (CRIM_NLM_DIRECT=1: the window-difference kernels; CRIM_NLM_CORR=1: correlation form without shared row products)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "image-processing_amd"))
@@ -12,4 +12,4 @@ else:   # the reference's 100 dataset images (decoded pixels committed beside th
 capi.filter_noise(imgs[:4])
 t = time.time(); out = capi.filter_noise(imgs, median_ksize=3, nlm_h=7, apply_sharpening=True); dt = time.time() - t
 import zlib
-print("%s: 100 images in %.1f ms: %.0f images/s, crc %08x" % ("direct" if os.environ.get("CRIM_NLM_DIRECT") else "correlation", 1e3 * dt, 100 / dt, zlib.crc32(out.tobytes())))
+print("%s: 100 images in %.1f ms: %.0f images/s, crc %08x" % ("differences" if os.environ.get("CRIM_NLM_DIRECT") else "correlation" if os.environ.get("CRIM_NLM_CORR") else "shared rows", 1e3 * dt, 100 / dt, zlib.crc32(out.tobytes())))
