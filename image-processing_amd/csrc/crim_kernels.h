@@ -2089,11 +2089,7 @@ void k_search_pipe(Params p) {
     // inadmissible anyway see those bytes.  Rows below the image are read as they come (the next
     // plane's or image's rows; the buffer ends in spare rows for the last image).  The offsets
     // are the same for all planes of a tile and advance by 32 rows per tile.
-#ifdef TIMING_RESIDENT   // timing build: every block reads the planes of one of 64 images (cache-resident), wrong results
-    const uint8_t* pl = p.planes + (size_t)(b & 63) * CRIM_NPL * H * Wp;
-#else
     const uint8_t* pl = p.planes + (size_t)b * CRIM_NPL * H * Wp;
-#endif
     const size_t plane_bytes = (size_t)H * Wp;
     // plane consumed by pass k of a tile: h digits, L, [a, b,] l digits
     auto plane_of = [](int k) { return k == 0 ? 6 : (k == NP - 1 ? 5 : k - 1); };
@@ -2316,9 +2312,6 @@ void k_search_pipe(Params p) {
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const int yy = r - 2 * s;
-#ifdef TIMING_MFMA_STEPS
-                if (s >= TIMING_MFMA_STEPS) continue;   // timing build: wrong sums, fewer matrix instructions
-#endif
                 if (yy >= 0 && yy < R)
                     acc[yy] = __builtin_amdgcn_mfma_i32_16x16x64_i8(F, Bf[s], acc[yy], 0, 0, 0);
             }
