@@ -2452,10 +2452,14 @@ void k_search_pipe(Params p) {
                     for (int yy = 0; yy < R; ++yy)
                         for (int jj = 0; jj < 4; ++jj) {
                             const int y = wy + win_row(yy), x = win_x(yy, jj);
-                            bool wok;
-                            if constexpr (SELECT) wok = window_valid_geom(p, 1, s_red[1 + 3], s_red[2 + 3], inv, mask, y, x);
-                            else wok = window_valid(p, d, inv, mask, y, x);
-                            const int ok = (y < ncy && x < ncx && wok) ? 1 : 0;
+                            // (only origins inside the candidate grid are looked at: the mask test reads the
+                            // window's pixels)
+                            bool wok = y < ncy && x < ncx;
+                            if (wok) {
+                                if constexpr (SELECT) wok = window_valid_geom(p, 1, s_red[1 + 3], s_red[2 + 3], inv, mask, y, x);
+                                else wok = window_valid(p, d, inv, mask, y, x);
+                            }
+                            const int ok = wok ? 1 : 0;
                             acc[yy][jj] = ok ? 0 : -POISON;
                             anyvalid |= ok;
                         }

@@ -182,6 +182,38 @@ def test_pipelined_and_plain_grey_search_agree_on_a_batch(monkeypatch):
     assert np.array_equal(res[1][0][5], oout) and np.array_equal(res[1][1][5], oconf)
 
 
+@pytest.mark.parametrize("p,colour", [(9, False), (9, True), (5, False), (7, True), (13, False)])
+def test_border_clipped_targets_without_selection_in_the_search(p, colour, monkeypatch):
+    """Holes that touch the image border give targets whose patch is clipped: the search then checks every
+    window against the mask itself (the validity map only knows full P x P windows).  With the selection in
+    its own launch (the arrangement of large batches) and hole corners in the image's last rows and columns,
+    so that the last tiles hold windows beyond the candidate grid -- those must not be looked at.  Single
+    images and a batch whose last image has the clipped targets."""
+    monkeypatch.setenv("CRIM_SELECT_IN_SEARCH", "0")
+    H, W = 70, 300
+    img = crim_synth.xray_like(H, W, 8100 + p, colour=colour)
+    m = np.zeros((H, W), np.uint8)
+    m[H - p - 3:, W - 2 * p:] = 1          # bottom-right corner
+    m[:p + 1, :p + 2] = 1                  # top-left corner
+    m[30:30 + p, 120:120 + p + 1] = 1      # and an interior hole
+    assert_same_as_oracle(img, m, p)
+    B = 4
+    imgs = np.stack([crim_synth.xray_like(H, W, 8200 + p + i, colour=colour) for i in range(B)])
+    masks = np.zeros((B, H, W), np.uint8)
+    for i in range(B - 1):
+        masks[i, 20:20 + p + i, 40 + 30 * i:40 + 30 * i + p + 2] = 1
+    masks[B - 1] = m
+    with capi.Engine(H, W, p, batch=B) as eng:
+        eng.upload(imgs, masks)
+        eng.run()
+        out, conf, _ = eng.download(want_conf=True)
+        traces = [eng.trace(i).copy() for i in range(B)]
+    for i in (0, B - 1):
+        oout, oconf, _, otr, n = c_oracle.run(imgs[i], masks[i], p)
+        assert np.array_equal(out[i], oout) and np.array_equal(conf[i], oconf), i
+        assert np.array_equal(traces[i], otr.astype(capi.ITER_REC_DTYPE)), i
+
+
 @pytest.mark.parametrize("flag", [capi.FLAG_PROFILE, capi.FLAG_PROFILE_SOLO])
 def test_profile_flags_count_every_search_launch(flag):
     H, W, B = 64, 72, 4
