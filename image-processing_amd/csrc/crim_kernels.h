@@ -37,7 +37,10 @@
     do {                                                                                    \
         if (threadIdx.x == 0 && blockIdx.x == (blk)) p.dbg[slot] = wall_clock64();          \
     } while (0)
+// the same under a condition (a tile in the middle of a block's walk)
+#define TSTAMP(cond, slot) do { if ((cond) && threadIdx.x == 0 && blockIdx.x == gridDim.x / 2 + 5) p.dbg[slot] = wall_clock64(); } while (0)
 #else
+#define TSTAMP(cond, slot) do {} while (0)
 #define STAMP_AT(blk, slot) do {} while (0)
 #define STAMP(slot) do {} while (0)
 #define STAMP_MID(slot) do {} while (0)
@@ -2372,6 +2375,8 @@ void k_search_pipe(Params p) {
         const bool more = t + 1 < T;
         bool wave_on = false;
         bool clean = false;
+        // (diagnostic build: the phases of the block's fourth tile, slots 40..52; tools/search_tile_stamps.py)
+        TSTAMP(t == 3, 40);
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             // ---- barrier before pass j: load j is waited for, counting the ring loads issued after
@@ -2381,6 +2386,7 @@ void k_search_pipe(Params p) {
             else if (j + 1 < NP) publish(NK);
             else if (more) publish(NK + 1);
             else publish(0);
+            TSTAMP(t == 3, 41 + 3 * (j < 3 ? j : 2));
             if (j >= 1) {
                 // pass j - 1 is over in every wave: its slot takes load j + 2
                 const int i = j + 2;
@@ -2467,6 +2473,7 @@ void k_search_pipe(Params p) {
                 }
                 wave_on = tile_any && wave_any;
             }
+            TSTAMP(t == 3, 42 + 3 * (j < 3 ? j : 2));
             // ---- pass j
             if (j == 1) {
 #pragma unroll
@@ -2489,6 +2496,7 @@ void k_search_pipe(Params p) {
                     plane_pass(slot_of(j), Bc);
                 }
             }
+            TSTAMP(t == 3, 43 + 3 * (j < 3 ? j : 2));
         }
 
         if (clean) {
@@ -2521,7 +2529,9 @@ void k_search_pipe(Params p) {
             if (u < (long long)__hip_atomic_load(&s_bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
                 atomicMin(&s_bound, (int)u);
         }
+        TSTAMP(t == 3, 50);
         publish_barrier<63>();                      // bounds posted; no ring load is waited for
+        TSTAMP(t == 3, 51);
         if (more) load_plane(plane_of(2), coff, slot_of(NP + 2));   // the last pass's slot takes load NP + 2
         if (t == 0) STAMP_MID(37);
         const int ub = __hip_atomic_load(&s_bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -2558,6 +2568,7 @@ void k_search_pipe(Params p) {
         }
         tbase += NP % 3;
         if (tbase >= 3) tbase -= 3;
+        TSTAMP(t == 3, 52);
     }
     publish_barrier<0>();
     if (tid == 0) {
