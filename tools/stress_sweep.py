@@ -2,7 +2,8 @@
 """Extended random parity sweep (GPU engine against the C oracle), larger and more varied than
 the one in the test suite: image sides 20..420 (several search tiles per row and column), every
 patch edge 3..17, grey / colour / noise / flat images, masks with border contact and salt, and
-the many-row-tiles-per-block walk of the pipelined search forced on or off.
+the many-row-tiles-per-block walk of the pipelined search forced on or off, and the iteration run as two, three
+or four launches.
 
     python tools/stress_sweep.py [--cases 200] [--seed 1]
 """
@@ -55,6 +56,15 @@ def main():
             m[0, 0] = 0
         os.environ["CRIM_PIPE_MIN_BLOCKS"] = "1" if k % 2 else "1024"
         os.environ["CRIM_PIPE_T"] = str(int(rng.choice([1, 2, 3, 8])))
+        # the iteration as two launches (default for a single image), three (CRIM_FUSED=0) or four (the
+        # selection in its own launch, as large batches run)
+        mode = int(rng.integers(0, 3))
+        for name in ("CRIM_FUSED", "CRIM_SELECT_IN_SEARCH"):
+            os.environ.pop(name, None)
+        if mode == 1:
+            os.environ["CRIM_FUSED"] = "0"
+        elif mode == 2:
+            os.environ["CRIM_SELECT_IN_SEARCH"] = "0"
         oout, oconf, _, otr, n = c_oracle.run(img, m, p)
         with capi.Engine(H, W, p) as eng:
             eng.upload(img, m)
@@ -71,8 +81,8 @@ def main():
               and np.array_equal(tr, otr.astype(capi.ITER_REC_DTYPE)))
         if not ok:
             bad += 1
-            print("case %d (H=%d W=%d p=%d kind=%d T=%s min=%s): MISMATCH" % (
-                k, H, W, p, kind, os.environ["CRIM_PIPE_T"], os.environ["CRIM_PIPE_MIN_BLOCKS"]), flush=True)
+            print("case %d (H=%d W=%d p=%d kind=%d T=%s min=%s launches=%d): MISMATCH" % (
+                k, H, W, p, kind, os.environ["CRIM_PIPE_T"], os.environ["CRIM_PIPE_MIN_BLOCKS"], 2 + mode), flush=True)
         if k % 20 == 19:
             print("%d cases, %d bad, %.0f s" % (k + 1, bad, time.time() - t0), flush=True)
     print("done: %d cases, %d bad" % (a.cases, bad))
