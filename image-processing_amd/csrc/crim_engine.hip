@@ -660,7 +660,7 @@ extern "C" int crim_create(int H, int W, int patch_size, int device, unsigned fl
 // Derives every cached field of images [first, first+count) from prm.bgr / prm.mask.
 static void launch_init(const Params& p, hipStream_t s, int first, int count) {
     hipLaunchKernelGGL(k_init_state, dim3((count + 63) / 64), dim3(64), 0, s, p, first, count);
-    dim3 grid(p.tnx, p.tny, count), block(256);
+    dim3 grid((p.W + IF_W - 1) / IF_W, p.tny, count), block(256);   // k_init_fields: strips of 16 rows x IF_W columns
     const size_t HW = (size_t)p.H * p.W;
     hipLaunchKernelGGL(k_init_pixels, dim3((unsigned)((HW + 1023) / 1024), count), block, 0, s, p, first);
     hipLaunchKernelGGL(k_init_fields, grid, block, 0, s, p, first);

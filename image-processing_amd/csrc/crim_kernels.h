@@ -499,84 +499,114 @@ __global__ __launch_bounds__(256) void k_init_pixels(Params p, int first) {
 }
 
 // Gradient field, window-validity map and the per-tile count of front pixels; needs the
-// normalised mask of the whole image.  One block per 16x16 tile.
+// normalised mask of the whole image.  One block per strip of 16 rows x 256 columns (a row of 16 tiles);
+// a thread owns one column of the strip and walks down its 16 rows, so every row is read and written
+// as 256 consecutive elements.
+#define IF_W 256
 __global__ __launch_bounds__(256) void k_init_fields(Params p, int first) {
     const int b = first + blockIdx.z;
-    const int y = blockIdx.y * CRIM_TILE + (threadIdx.x >> 4);
-    const int x = blockIdx.x * CRIM_TILE + (threadIdx.x & 15);
-    const size_t HW = (size_t)p.H * p.W;
+    const int x0 = blockIdx.x * IF_W, y0 = blockIdx.y * CRIM_TILE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = p.H, W = p.W, P = p.P;
+    const size_t HW = (size_t)H * W;
     const uint8_t* mk = p.mask + b * HW;
-    // Mask rows of the tile grown by P-1 to the right and below as bit rows (bit j = pixel
-    // tx0 + j masked or beyond the image), by wave ballots; a window is inadmissible when the OR of
+    const uint8_t* gr = p.grey + b * HW;
+    // Mask rows of the strip grown by P-1 to the right and below as bit rows (bit j of word k = pixel
+    // x0 + 64 k + j masked or beyond the image), by wave ballots; a window is inadmissible when the OR of
     // its P rows has a bit set among its P columns.
-    __shared__ unsigned long long s_rowbits[CRIM_TILE + CRIM_PMAX - 1];
-    // the tile grown by one pixel: the mask with BORDER_REFLECT_101 (front weight), and the grey
+    constexpr int NRM = CRIM_TILE + CRIM_PMAX - 1;
+    __shared__ unsigned long long s_bits[NRM][5];
+    // the strip grown by one pixel: the mask with BORDER_REFLECT_101 (front weight), and the grey
     // values with masked pixels read as 0 (gradient; positions beyond the image are never used)
-    constexpr int TS = CRIM_TILE + 2;
-    __shared__ uint8_t s_mk[TS * TS], s_gg[TS * TS];
+    constexpr int TSW = IF_W + 2, TSP = IF_W + 8;
+    __shared__ uint8_t s_mk[(CRIM_TILE + 2) * TSP], s_gg[(CRIM_TILE + 2) * TSP];
+    static_assert(TSW <= 512, "two columns per thread at most");
     {
-        const int tx0 = blockIdx.x * CRIM_TILE, ty0 = blockIdx.y * CRIM_TILE;
-        const uint8_t* gr = p.grey + b * HW;
-        for (int e = threadIdx.x; e < TS * TS; e += 256) {
-            const int i = e / TS, j = e - i * TS;
-            const int yy = imin(imax(ty0 - 1 + i, -1), p.H), xx = imin(imax(tx0 - 1 + j, -1), p.W);
-            s_mk[e] = mk[(size_t)reflect101(yy, p.H) * p.W + reflect101(xx, p.W)];
-            const size_t q = (size_t)imin(imax(yy, 0), p.H - 1) * p.W + imin(imax(xx, 0), p.W - 1);
-            s_gg[e] = mk[q] ? (uint8_t)0 : gr[q];
+        // (this thread's columns: tid, and for the first TSW - 256 threads tid + 256)
+        const int xx0 = imin(imax(x0 - 1 + tid, -1), W), xx1 = imin(imax(x0 - 1 + tid + 256, -1), W);
+        const int rx0 = reflect101(xx0, W), rx1 = reflect101(xx1, W);
+        const int cx0 = imin(imax(xx0, 0), W - 1), cx1 = imin(imax(xx1, 0), W - 1);
+#pragma unroll 6
+        for (int i = 0; i < CRIM_TILE + 2; ++i) {
+            const int yy = imin(imax(y0 - 1 + i, -1), H);
+            const size_t rrow = (size_t)reflect101(yy, H) * W, crow = (size_t)imin(imax(yy, 0), H - 1) * W;
+            s_mk[i * TSP + tid] = mk[rrow + rx0];
+            s_gg[i * TSP + tid] = mk[crow + cx0] ? (uint8_t)0 : gr[crow + cx0];
+            if (tid < TSW - 256) {
+                s_mk[i * TSP + tid + 256] = mk[rrow + rx1];
+                s_gg[i * TSP + tid + 256] = mk[crow + cx1] ? (uint8_t)0 : gr[crow + cx1];
+            }
         }
     }
-    {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const int tx0 = blockIdx.x * CRIM_TILE, ty0 = blockIdx.y * CRIM_TILE;
-        const int nrows = CRIM_TILE + p.P - 1;
-        const int xx = tx0 + lane;
-        for (int r = wave; r < nrows; r += 4) {
-            const int yy = ty0 + r;
-            bool m = false;
-            if (lane < nrows) m = (yy >= p.H || xx >= p.W) ? true : mk[(size_t)yy * p.W + xx] != 0;
-            const unsigned long long bal = __ballot(m);
-            if (lane == 0) s_rowbits[r] = bal;
+    const int nrows = CRIM_TILE + P - 1;
+    for (int r0 = 0; r0 < nrows; r0 += 8) {   // eight rows' loads travel together
+        const int xa = x0 + tid, xb = x0 + IF_W + lane;
+        bool m[8], m2[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int yy = y0 + r0 + k;
+            const bool out = yy >= H || r0 + k >= nrows;
+            m[k] = (out || xa >= W) ? true : mk[(size_t)yy * W + xa] != 0;
+            m2[k] = true;
+            if (wave == 0) m2[k] = (out || xb >= W) ? true : mk[(size_t)yy * W + xb] != 0;   // right of the strip
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned long long bal = __ballot(m[k]), bal2 = __ballot(m2[k]);
+            if (lane == 0 && r0 + k < nrows) {
+                s_bits[r0 + k][wave] = bal;
+                if (wave == 0) s_bits[r0 + k][4] = bal2;
+            }
         }
     }
     __syncthreads();
-    int isfront = 0, inv_bit = 1;
-    if (y < p.H && x < p.W) {
-        const int py = threadIdx.x >> 4, px = threadIdx.x & 15;
-        {
-            // np.gradient (:174): central differences, one-sided at the image border (grad_packed)
-            const uint8_t* g0 = s_gg + (py + 1) * TS + (px + 1);
-            const int H = p.H, W = p.W;
-            int gy2, gx2;
-            if (H == 1) gy2 = 0;
-            else if (y == 0) gy2 = 2 * ((int)g0[TS] - (int)g0[0]);
-            else if (y == H - 1) gy2 = 2 * ((int)g0[0] - (int)g0[-TS]);
-            else gy2 = (int)g0[TS] - (int)g0[-TS];
-            if (W == 1) gx2 = 0;
-            else if (x == 0) gx2 = 2 * ((int)g0[1] - (int)g0[0]);
-            else if (x == W - 1) gx2 = 2 * ((int)g0[0] - (int)g0[-1]);
-            else gx2 = (int)g0[1] - (int)g0[-1];
-            p.grad[b * HW + (size_t)y * p.W + x] = (gy2 & 0xffff) | (int)((unsigned)gx2 << 16);
-        }
-        unsigned long long rows = 0;
-        for (int i = 0; i < p.P; ++i) rows |= s_rowbits[py + i];
-        const int inv = ((rows >> px) & ((1ull << p.P) - 1ull)) != 0;
-        p.invalid[((size_t)b * p.H + y) * p.Wi + x] = (uint8_t)inv;
-        inv_bit = inv;
-        const uint8_t* m0 = s_mk + py * TS + px;   // top-left of the 3x3 neighbourhood
-        isfront = m0[TS + 1] == 0 && (m0[0] + m0[2] + m0[2 * TS] + m0[2 * TS + 2]) > 0;
+    const int x = x0 + tid;
+    const unsigned long long pm = (1ull << P) - 1ull;
+    // bit r: the P columns from x of mask row y0 + r hold a masked pixel
+    unsigned long long hbits = 0;
+    for (int r = 0; r < nrows; ++r) {
+        unsigned long long lo = s_bits[r][wave] >> lane;
+        if (lane) lo |= s_bits[r][wave + 1] << (64 - lane);
+        hbits |= (unsigned long long)((lo & pm) != 0) << r;
     }
-    {
-        // bitmap form: a wave covers 4 tile rows of 16 origins; origins beyond the image stay 1
+    int cnt = 0;
+    for (int py = 0; py < CRIM_TILE; ++py) {
+        const int y = y0 + py;
+        int inv_bit = 1;
+        if (y < H && x < W) {
+            {
+                // np.gradient (:174): central differences, one-sided at the image border (grad_packed)
+                const uint8_t* g0 = s_gg + (py + 1) * TSP + (tid + 1);
+                int gy2, gx2;
+                if (H == 1) gy2 = 0;
+                else if (y == 0) gy2 = 2 * ((int)g0[TSP] - (int)g0[0]);
+                else if (y == H - 1) gy2 = 2 * ((int)g0[0] - (int)g0[-TSP]);
+                else gy2 = (int)g0[TSP] - (int)g0[-TSP];
+                if (W == 1) gx2 = 0;
+                else if (x == 0) gx2 = 2 * ((int)g0[1] - (int)g0[0]);
+                else if (x == W - 1) gx2 = 2 * ((int)g0[0] - (int)g0[-1]);
+                else gx2 = (int)g0[1] - (int)g0[-1];
+                p.grad[b * HW + (size_t)y * W + x] = (gy2 & 0xffff) | (int)((unsigned)gx2 << 16);
+            }
+            const int inv = ((hbits >> py) & pm) != 0;
+            p.invalid[((size_t)b * H + y) * p.Wi + x] = (uint8_t)inv;
+            inv_bit = inv;
+            const uint8_t* m0 = s_mk + py * TSP + tid;   // top-left of the 3x3 neighbourhood
+            cnt += (m0[TSP + 1] == 0 && (m0[0] + m0[2] + m0[2 * TSP] + m0[2 * TSP + 2]) > 0) ? 1 : 0;
+        }
+        // bitmap form: a wave covers 64 origins of the row; origins beyond the image stay 1
         const unsigned long long bal = __ballot(inv_bit);
-        const int lane = threadIdx.x & 63;
-        if ((lane & 15) == 0 && y < p.H) {
-            unsigned short* row = (unsigned short*)(p.invbits + ((size_t)b * p.H + y) * p.Wb);
-            row[blockIdx.x] = (unsigned short)(bal >> (lane & 48));
-        }
+        const int word = (x0 >> 6) + wave;
+        if (lane == 0 && y < H && word < p.Wb) p.invbits[((size_t)b * H + y) * p.Wb + word] = bal;
     }
-    const int cnt = __syncthreads_count(isfront);
-    if (threadIdx.x == 0) {
-        const int tile = blockIdx.y * p.tnx + blockIdx.x;
+    // front pixels per 16 x 16 tile: the 16 columns of a tile are 16 neighbouring lanes
+    cnt += __shfl_xor(cnt, 1);
+    cnt += __shfl_xor(cnt, 2);
+    cnt += __shfl_xor(cnt, 4);
+    cnt += __shfl_xor(cnt, 8);
+    const int tX = (x0 >> 4) + (tid >> 4);
+    if ((tid & 15) == 0 && tX < p.tnx) {
+        const int tile = blockIdx.y * p.tnx + tX;
         p.tfront[(size_t)b * p.tnx * p.tny + tile] = cnt;
         if (cnt) p.tlist[(size_t)b * 2 * p.tcap + atomicAdd(&p.st[b].tcount, 1u)] = tile;   // buffer 0 (tlsel = 0)
     }
