@@ -262,6 +262,13 @@ static void close_host_exchange(crim_engine* h) {
 
 // Search over block rows [sy0, sy0 + rows) of the window-origin grid (all rows when rows < 0).
 // Does the search launch also do the select stage's work?  (only the pipelined matrix-core kernel can)
+// The target selection as a launch of its own: one wave per image where the patch has at most 128 elements.
+static void launch_select(const Params& p, hipStream_t s) {
+    constexpr int NEL256 = (CRIM_PMAX * CRIM_PMAX + 255) / 256;
+    if (p.P * p.P <= 128 && !getenv("CRIM_SELECT_256")) hipLaunchKernelGGL((k_select<64, 2>), dim3(p.B), dim3(64), 0, s, p);
+    else hipLaunchKernelGGL((k_select<256, NEL256>), dim3(p.B), dim3(256), 0, s, p);
+}
+
 static bool search_selects(const Params& p) {
     return p.selsearch && !p.generic && !p.dot4 && p.pipe_t > 0 && p.P >= 3 && p.P <= 15 && (p.P & 1);
 }
@@ -403,7 +410,7 @@ static void launch_iteration(const Params& p, hipStream_t s, hipEvent_t ev0 = nu
                              hipEvent_t ev1 = nullptr) {
     launch_priority(p, s);
     const bool sel = search_selects(p);
-    if (!sel) hipLaunchKernelGGL(k_select, dim3(p.B), dim3(256), 0, s, p);
+    if (!sel) launch_select(p, s);
     if (ev0) (void)hipEventRecord(ev0, s);
     launch_search(p, s, 0, -1, sel);
     if (ev1) (void)hipEventRecord(ev1, s);
@@ -868,7 +875,7 @@ static int launch_split_iteration(crim_engine* h, const Params& p, hipStream_t s
     const int rpp = split_rows_per_part(p, parts);
     if (first_half) {
         if (!p.fused) launch_priority(p, s);
-        if (!sel) hipLaunchKernelGGL(k_select, dim3(p.B), dim3(256), 0, s, p);
+        if (!sel) launch_select(p, s);
         for (int part = 0; part < parts; ++part) {
             if (h->split_rank >= 0 && part != h->split_rank) continue;
             const int y0 = std::min(part * rpp, p.sny), y1 = std::min(y0 + rpp, p.sny);

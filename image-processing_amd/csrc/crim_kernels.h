@@ -1110,7 +1110,10 @@ __global__ __launch_bounds__(256) void k_fields(Params p, int b, uint8_t* front,
 // iteration kernel 2: pick the target pixel, build the template descriptor
 // ------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void k_select(Params p) {
+// NT threads per image: 256 in general; 64 (one wave, NEL = 2 patch elements per lane) for patch edges up to
+// 11, where a batch of thousands of images then has every block resident at once.
+template <int NT, int NEL>
+__global__ __launch_bounds__(NT) void k_select(Params p) {
     const int b = p.b0 + blockIdx.x;
     ImgState* st = p.st + b;
     Desc* d = p.desc + b;
@@ -1122,7 +1125,7 @@ __global__ __launch_bounds__(256) void k_select(Params p) {
     constexpr int NSPEC = 2;
     PEntry spec[NSPEC];
 #pragma unroll
-    for (int k = 0; k < NSPEC; ++k) spec[k] = pl[imin(tid + 256 * k, p.pgrid - 1)];   // used only when in range
+    for (int k = 0; k < NSPEC; ++k) spec[k] = pl[imin(tid + NT * k, p.pgrid - 1)];   // used only when in range
     const int live = st->live;
     const unsigned n = (unsigned)p.pgrid;   // one slot per wave of the priority stage
     const int cur = st->cur;
@@ -1149,10 +1152,10 @@ __global__ __launch_bounds__(256) void k_select(Params p) {
     int bestI = 0x7fffffff;
 #pragma unroll
     for (int k = 0; k < NSPEC; ++k)
-        if ((unsigned)(tid + 256 * k) < n && better_prio(spec[k].prio, spec[k].pos, bestP, bestI)) {
+        if ((unsigned)(tid + NT * k) < n && better_prio(spec[k].prio, spec[k].pos, bestP, bestI)) {
             bestP = spec[k].prio; bestI = spec[k].pos;
         }
-    for (unsigned i = tid + 256 * NSPEC; i < n; i += 256) {
+    for (unsigned i = tid + NT * NSPEC; i < n; i += NT) {
         const PEntry e = pl[i];
         if (better_prio(e.prio, e.pos, bestP, bestI)) { bestP = e.prio; bestI = e.pos; }
     }
@@ -1161,7 +1164,7 @@ __global__ __launch_bounds__(256) void k_select(Params p) {
     if (tid == 0) { s_soff = 0; s_rowmask = 0; s_chmask = 0; s_nk = 0; }
     __syncthreads();
     if (tid == 0) {
-        for (int w = 1; w < 4; ++w)
+        for (int w = 1; w < NT / 64; ++w)
             if (better_prio(s_bp[w], s_bi[w], bestP, bestI)) { bestP = s_bp[w]; bestI = s_bi[w]; }
         // empty front: the priority map is all zeros and np.argmax returns index 0
         s_target = (bestP > 0.0) ? bestI : 0;
@@ -1180,11 +1183,11 @@ __global__ __launch_bounds__(256) void k_select(Params p) {
     // unconditional, from clamped positions, so that they travel together.
     const double cnew_t = p.conf[((size_t)b * 2 + (cur ^ 1)) * HW + pos];
     const bool mfma_path = P <= MS_PMAX && !p.dot4 && !p.generic;
-    constexpr int NEL = (CRIM_PMAX * CRIM_PMAX + 255) / 256;
+    // (the launch site picks NT and NEL such that NT * NEL covers the patch)
     int em[NEL], e0[NEL], e1[NEL], e2[NEL];
 #pragma unroll
     for (int q = 0; q < NEL; ++q) {
-        const int e = imin(tid + 256 * q, P * P - 1);
+        const int e = imin(tid + NT * q, P * P - 1);
         const int i = e / P, j = e - i * P;
         const int yy = imin(r0 + i, H - 1), xx = imin(c0 + j, W - 1);
         em[q] = mask[(size_t)yy * W + xx];
@@ -1198,7 +1201,7 @@ __global__ __launch_bounds__(256) void k_select(Params p) {
     int soff_local = 0, nk_local = 0, rowm_local = 0, chm_local = 0;
 #pragma unroll
     for (int q = 0; q < NEL; ++q) {
-        const int e = tid + 256 * q;
+        const int e = tid + NT * q;
         if (e >= P * P) continue;
         const int i = e / P, j = e - i * P;
         int k = 0, t0 = 0, t1 = 0, t2 = 0;
@@ -1237,7 +1240,7 @@ __global__ __launch_bounds__(256) void k_select(Params p) {
         // shifted template rows of the vector search: dword j of shift s covers template columns
         // 4j-s .. 4j-s+3
         const int total = 5 * P * 4 * ND;
-        for (int e = tid; e < total; e += 256) {
+        for (int e = tid; e < total; e += NT) {
             const int j = e % ND;
             const int s = (e / ND) & 3;
             const int i = (e / (ND * 4)) % P;
