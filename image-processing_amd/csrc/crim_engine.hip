@@ -665,17 +665,19 @@ extern "C" int crim_create(int H, int W, int patch_size, int device, unsigned fl
 }
 
 // Derives every cached field of images [first, first+count) from prm.bgr / prm.mask.
-static void launch_init(const Params& p, hipStream_t s, int first, int count) {
+// (src_bgr / src_mask: dense device images the pixel kernel reads instead of prm.bgr / prm.mask, which it then fills)
+static void launch_init(const Params& p, hipStream_t s, int first, int count, const uint8_t* src_bgr = nullptr,
+                        const uint8_t* src_mask = nullptr) {
     hipLaunchKernelGGL(k_init_state, dim3((count + 63) / 64), dim3(64), 0, s, p, first, count);
     dim3 grid((p.W + IF_W - 1) / IF_W, p.tny, count), block(256);   // k_init_fields: strips of 16 rows x IF_W columns
     const size_t HW = (size_t)p.H * p.W;
-    hipLaunchKernelGGL(k_init_pixels, dim3((unsigned)((HW + 1023) / 1024), count), block, 0, s, p, first);
+    hipLaunchKernelGGL(k_init_pixels, dim3((unsigned)((HW + 1023) / 1024), count), block, 0, s, p, first, src_bgr, src_mask);
     hipLaunchKernelGGL(k_init_fields, grid, block, 0, s, p, first);
 }
 
-static int init_images(crim_engine* h, int first, int count) {
+static int init_images(crim_engine* h, int first, int count, const uint8_t* src_bgr = nullptr, const uint8_t* src_mask = nullptr) {
     const Params& p = h->prm;
-    launch_init(p, h->stream, first, count);
+    launch_init(p, h->stream, first, count, src_bgr, src_mask);
     HIP_TRY(hipGetLastError());
     for (int i = 0; i < count; ++i) h->uploaded[first + i] = true;
     h->prepared = false;
@@ -779,11 +781,19 @@ extern "C" int crim_upload_device(crim_t* h, int first, int count, const void* d
         return fail(CRIM_ERR_ARG, "crim_upload_device: images [%d,%d) outside batch of %d", first, first + count, p.B);
     HIP_TRY(hipSetDevice(h->device));
     const size_t HW = (size_t)p.H * p.W;
-    HIP_TRY(hipMemcpyAsync(p.bgr + (size_t)first * HW * 3, d_bgr, (size_t)count * HW * 3,
-                           hipMemcpyDeviceToDevice, h->stream));
-    HIP_TRY(hipMemcpyAsync(p.mask + (size_t)first * HW, d_mask, (size_t)count * HW,
-                           hipMemcpyDeviceToDevice, h->stream));
-    return init_images(h, first, count);
+    // (no copy beforehand: the kernel that derives the planes reads the caller's buffers and fills the engine's;
+    // the caller's buffers must stay untouched until the stream has passed the upload, as with the copy before)
+    const uint8_t* sb = (const uint8_t*)d_bgr;
+    const uint8_t* sm = (const uint8_t*)d_mask;
+    if (sb == p.bgr + (size_t)first * HW * 3) sb = nullptr;      // already in place
+    if (sm == p.mask + (size_t)first * HW) sm = nullptr;
+    const bool aligned = ((uintptr_t)d_bgr & 3) == 0 && ((uintptr_t)d_mask & 3) == 0;   // the kernel reads dwords
+    if ((sb == nullptr) != (sm == nullptr) || !aligned) {        // one of the two in place, or odd addresses: copy as before
+        if (sb) HIP_TRY(hipMemcpyAsync(p.bgr + (size_t)first * HW * 3, sb, (size_t)count * HW * 3, hipMemcpyDeviceToDevice, h->stream));
+        if (sm) HIP_TRY(hipMemcpyAsync(p.mask + (size_t)first * HW, sm, (size_t)count * HW, hipMemcpyDeviceToDevice, h->stream));
+        sb = sm = nullptr;
+    }
+    return init_images(h, first, count, sb, sm);
 }
 
 // Sizes the trace buffer from what was uploaded, then (re)builds the iteration graphs.

@@ -424,12 +424,18 @@ __global__ __launch_bounds__(256) void k_build_mask(Params p, int first, int thr
 // consecutive pixels of the flattened image (1024 per block): dword mask / grey / plane accesses
 // and 32-byte confidence stores instead of single bytes.  Four pixels stay in one row, and their
 // plane bytes in one aligned dword, when W is a multiple of 4; other widths go pixel by pixel.
-__global__ __launch_bounds__(256) void k_init_pixels(Params p, int first) {
+// src_bgr / src_mask: the uploaded images where they are not in the engine's buffers yet (device-to-device
+// uploads: images first .. of the call, dense) -- the kernel then fills prm.bgr / prm.mask itself instead of
+// a copy made beforehand; null: the buffers already hold them.
+__global__ __launch_bounds__(256) void k_init_pixels(Params p, int first, const uint8_t* __restrict__ src_bgr,
+                                                     const uint8_t* __restrict__ src_mask) {
     const int b = first + blockIdx.y;
     const size_t HW = (size_t)p.H * p.W;
     const size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
     uint8_t* mk = p.mask + b * HW;
-    const uint8_t* bgr = p.bgr + b * HW * 3;
+    uint8_t* bgr_out = p.bgr + b * HW * 3;
+    const uint8_t* bgr = src_bgr ? src_bgr + (size_t)blockIdx.y * HW * 3 : bgr_out;
+    const uint8_t* mk_in = src_mask ? src_mask + (size_t)blockIdx.y * HW : mk;
     uint8_t* grey = p.grey + b * HW;
     double* c0 = p.conf + (b * 2 + 0) * HW;
     double* c1 = p.conf + (b * 2 + 1) * HW;
@@ -442,9 +448,12 @@ __global__ __launch_bounds__(256) void k_init_pixels(Params p, int first) {
         return (uint8_t)((B_ * 3735 + G_ * 19235 + R_ * 9798 + 16384) >> 15);
     };
     if ((p.W & 3) == 0 && i0 + 4 <= HW) {
-        const uint32_t m4 = *(const uint32_t*)(mk + i0);
+        const uint32_t m4 = *(const uint32_t*)(mk_in + i0);
         const uint32_t q0 = *(const uint32_t*)(bgr + 3 * i0), q1 = *(const uint32_t*)(bgr + 3 * i0 + 4),
                        q2 = *(const uint32_t*)(bgr + 3 * i0 + 8);
+        if (src_bgr) {
+            *(uint32_t*)(bgr_out + 3 * i0) = q0; *(uint32_t*)(bgr_out + 3 * i0 + 4) = q1; *(uint32_t*)(bgr_out + 3 * i0 + 8) = q2;
+        }
         const uint8_t px[12] = {(uint8_t)q0, (uint8_t)(q0 >> 8), (uint8_t)(q0 >> 16), (uint8_t)(q0 >> 24),
                                 (uint8_t)q1, (uint8_t)(q1 >> 8), (uint8_t)(q1 >> 16), (uint8_t)(q1 >> 24),
                                 (uint8_t)q2, (uint8_t)(q2 >> 8), (uint8_t)(q2 >> 16), (uint8_t)(q2 >> 24)};
@@ -474,14 +483,16 @@ __global__ __launch_bounds__(256) void k_init_pixels(Params p, int first) {
         for (int j = 0; j < 4; ++j) {
             const size_t i = i0 + j;
             if (i >= HW) break;
-            const int m = mk[i] ? 1 : 0;
+            const int m = mk_in[i] ? 1 : 0;
             cnt += m;
             mk[i] = (uint8_t)m;
             const double c = 1.0 - (double)m;
             c0[i] = c;
             c1[i] = c;
             uint8_t pl[CRIM_NPL];
-            grey[i] = one(bgr[3 * i], bgr[3 * i + 1], bgr[3 * i + 2], pl);
+            const uint8_t cb = bgr[3 * i], cg = bgr[3 * i + 1], cr = bgr[3 * i + 2];
+            if (src_bgr) { bgr_out[3 * i] = cb; bgr_out[3 * i + 1] = cg; bgr_out[3 * i + 2] = cr; }
+            grey[i] = one(cb, cg, cr, pl);
             const size_t y = i / p.W, x = i - y * p.W;
             for (int k2 = 0; k2 < CRIM_NPL; ++k2) planes[k2 * PS + y * p.Wp + x] = pl[k2];
         }
