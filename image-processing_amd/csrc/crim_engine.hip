@@ -618,6 +618,9 @@ extern "C" int crim_create_batch(int batch, int H, int W, int patch_size, int de
     if (e == hipSuccess) e = hipMemset(p.tlist, 0, Bz * 2 * p.tcap * sizeof(int));
     if (e == hipSuccess) e = hipMemset(p.dbg, 0, kDbgSlots * sizeof(long long));
     if (e == hipSuccess) e = hipMemset(p.desc, 0, Bz * sizeof(Desc));
+    // (memsets of device memory need not have finished when they return, and the engine's streams do not wait
+    // for the stream they ran on: an upload right after this call must not overtake them)
+    if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
         const int code = fail(e == hipErrorOutOfMemory ? CRIM_ERR_NOMEM : CRIM_ERR_HIP,
                               "crim_create: %s", hipGetErrorString(e));

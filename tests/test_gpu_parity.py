@@ -214,6 +214,44 @@ def test_border_clipped_targets_without_selection_in_the_search(p, colour, monke
         assert np.array_equal(traces[i], otr.astype(capi.ITER_REC_DTYPE)), i
 
 
+def test_engines_created_one_after_another_with_device_uploads():
+    """An engine created where another one of the same size has just been destroyed gets that one's memory,
+    stale contents included, and its creation clears state with memsets that may still be running when the call
+    returns: an upload from device buffers issued right away must find them done (it once overtook them and
+    lost the loop state it had just written -- on batches of thousands of 256 x 256 images, where the memsets
+    take a millisecond).  Three engines in a row on such a batch, a few iterations each: every one must
+    advance exactly as the first, and the first as the oracle."""
+    from helpers import HipBuffers
+    B, H, W, iters = 8192, 256, 256, 3
+    base = [(crim_synth.xray_like(H, W, 8300 + i), crim_synth.blob_mask(H, W, 8300 + i, 0.10, 9)) for i in range(8)]
+    imgs = np.stack([base[i % 8][0] for i in range(B)])
+    masks = np.stack([base[i % 8][1] for i in range(B)])
+    dev = HipBuffers()
+    try:
+        d_img, d_mask, d_out = dev.to_device(imgs), dev.to_device(masks), dev.zeros(imgs.nbytes)
+        del imgs, masks
+        runs = []
+        for k in range(3):
+            with capi.Engine(H, W, 9, batch=B, flags=capi.FLAG_NO_TRACE) as eng:
+                eng.upload_device(d_img, d_mask)
+                it, rem = eng.run(max_iters=iters)
+                eng.download_device(d_out)
+                first = dev.to_host(d_out, (8, H, W, 3))
+                last = eng.download(B - 8, 8)[0]
+                runs.append((it, rem, first, last))
+    finally:
+        dev.free_all()
+    it0, rem0, first0, last0 = runs[0]
+    assert it0 == iters and rem0 > 0
+    for i in (0, 5):
+        want = c_oracle.run(base[i][0], base[i][1], 9, max_iters=iters)[0]
+        assert np.array_equal(first0[i], want) and np.array_equal(last0[i], want), i
+    for k in (1, 2):
+        it, rem, first, last = runs[k]
+        assert (it, rem) == (it0, rem0), (k, it, rem, it0, rem0)
+        assert np.array_equal(first, first0) and np.array_equal(last, last0), k
+
+
 @pytest.mark.parametrize("flag", [capi.FLAG_PROFILE, capi.FLAG_PROFILE_SOLO])
 def test_profile_flags_count_every_search_launch(flag):
     H, W, B = 64, 72, 4
