@@ -267,6 +267,11 @@ def search_roofline(capi, h, w, patch, batch, upload, kernel, planes, hbm_reside
         upload(pe)
         pe.run(max_iters)
         ms, launches, evals = pe.profile()
+    if ms <= 0.0 or launches <= 0:
+        # (a side pass that recorded nothing must not cost the whole line; the figure is then missing, visibly)
+        return {"kernel": kernel, "error": "the profiling pass recorded no search launch (%r ms, %r launches)" % (ms, launches),
+                "bound": "hbm" if hbm_resident else "mfma", "achieved": None, "peak": None, "unit": None, "frac": None,
+                "avg_launch_us": None, "traffic": traffic}, 0.0
     P = 2 * ((patch - 1) // 2) + 1
     windows = (h - P + 1) * (w - P + 1)
     bytes_per_window = (planes + 0.125) * h * w / windows
@@ -447,7 +452,7 @@ def config_large(capi, device, side, patch, config_index, profile_iters=1500):
             "launches_us": split,
             "evals_per_s_whole_iteration": windows * it / dt,
             "evals_per_s_per_gpu": evals_s,
-            "search_share_of_iteration": roof["avg_launch_us"] / (1e6 * dt / max(it, 1)),
+            "search_share_of_iteration": (roof["avg_launch_us"] / (1e6 * dt / max(it, 1))) if roof.get("avg_launch_us") else None,
             "completed_and_known_pixels_untouched": ok,
             "cpu_port_s_per_iteration": cpu_s,
             "cpu_port_note": "C oracle, first 2 iterations, one core; a full CPU run would take "
