@@ -60,8 +60,8 @@ static int fail(int code, const char* fmt, ...) {
 namespace {
 
 struct LabTables {
-    uint16_t gamma[256];
-    uint16_t cbrt_[3072];
+    uint16_t gamma[CRIM_GAMMA_N];
+    uint16_t cbrt_[CRIM_CBRT_N];
     int32_t coef[9];
 };
 

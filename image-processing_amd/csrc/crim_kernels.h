@@ -364,11 +364,13 @@ __device__ __forceinline__ int grad_packed(const uint8_t* grey, const uint8_t* m
 // search planes derived from it: Lab - 128 per channel and Q = sum (Lab-128)^2 split as
 // Q % 255 and Q / 255, so that sum k*Q = dot(Q%255, k) + dot(Q/255, 255*k) stays in byte dot
 // products.
-__device__ __forceinline__ void lab_planes(const Params& p, int B_, int G_, int R_, uint8_t out[CRIM_NPL]) {
-    const int b = p.gamma_tab[B_], g = p.gamma_tab[G_], r = p.gamma_tab[R_];
-    const int fX = p.cbrt_tab[(b * p.coef[0] + g * p.coef[1] + r * p.coef[2] + 2048) >> 12];
-    const int fY = p.cbrt_tab[(b * p.coef[3] + g * p.coef[4] + r * p.coef[5] + 2048) >> 12];
-    const int fZ = p.cbrt_tab[(b * p.coef[6] + g * p.coef[7] + r * p.coef[8] + 2048) >> 12];
+// (gamma_tab, cbrt_tab: the two look-up tables, wherever the caller keeps them)
+__device__ __forceinline__ void lab_planes(const Params& p, const uint16_t* gamma_tab, const uint16_t* cbrt_tab,
+                                           int B_, int G_, int R_, uint8_t out[CRIM_NPL]) {
+    const int b = gamma_tab[B_], g = gamma_tab[G_], r = gamma_tab[R_];
+    const int fX = cbrt_tab[(b * p.coef[0] + g * p.coef[1] + r * p.coef[2] + 2048) >> 12];
+    const int fY = cbrt_tab[(b * p.coef[3] + g * p.coef[4] + r * p.coef[5] + 2048) >> 12];
+    const int fZ = cbrt_tab[(b * p.coef[6] + g * p.coef[7] + r * p.coef[8] + 2048) >> 12];
     int L = (296 * fY - 1336934 + 16384) >> 15;
     int a = (500 * (fX - fY) + 128 * 32768 + 16384) >> 15;
     int bb = (200 * (fY - fZ) + 128 * 32768 + 16384) >> 15;
@@ -442,8 +444,13 @@ __global__ __launch_bounds__(256) void k_init_pixels(Params p, int first, const 
     uint8_t* planes = p.planes + (size_t)b * CRIM_NPL * p.H * p.Wp;
     const size_t PS = (size_t)p.H * p.Wp;
     int cnt = 0, chroma = 0;
+    // the two tables of the Lab conversion in LDS: 24 look-ups per thread, scattered over 6.5 KB
+    __shared__ uint16_t s_gamma[CRIM_GAMMA_N], s_cbrt[CRIM_CBRT_N];
+    for (int e = threadIdx.x; e < CRIM_GAMMA_N / 2; e += 256) ((uint32_t*)s_gamma)[e] = ((const uint32_t*)p.gamma_tab)[e];
+    for (int e = threadIdx.x; e < CRIM_CBRT_N / 2; e += 256) ((uint32_t*)s_cbrt)[e] = ((const uint32_t*)p.cbrt_tab)[e];
+    __syncthreads();
     auto one = [&](int B_, int G_, int R_, uint8_t pl[CRIM_NPL]) -> uint8_t {
-        lab_planes(p, B_, G_, R_, pl);
+        lab_planes(p, s_gamma, s_cbrt, B_, G_, R_, pl);
         chroma |= (pl[1] | pl[2]) ? 1 : 0;
         return (uint8_t)((B_ * 3735 + G_ * 19235 + R_ * 9798 + 16384) >> 15);
     };

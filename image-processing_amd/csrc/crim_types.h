@@ -16,6 +16,9 @@
 
 // Matrix-core search tiling: a 256-thread block scores MS_W x MS_ROWS window origins; each of its
 // 4 waves owns MS_R consecutive origin rows.  Patch edges up to MS_PMAX.
+// entries of the Lab conversion's look-up tables (gamma per 8-bit value; cube root per 12-bit linear value)
+#define CRIM_GAMMA_N 256
+#define CRIM_CBRT_N 3072
 #define MS_W 256
 #define MS_R 8
 #define MS_ROWS (4 * MS_R)
