@@ -91,7 +91,9 @@ int crim_upload_batch(crim_t* h, int first, int count, const uint8_t* bgr, ptrdi
  * pixel frame cleared, one dilation_size x dilation_size (4) box dilation, then {0,1}. */
 int crim_upload_automask(crim_t* h, int first, int count, const uint8_t* bgr, ptrdiff_t image_stride,
                          ptrdiff_t row_stride, int threshold, int border_width, int dilation_size);
-/* Same, from dense device buffers ([count][H][W][3] and [count][H][W]) on the engine's GPU. */
+/* Same, from dense device buffers ([count][H][W][3] and [count][H][W]) on the engine's GPU.  The
+ * buffers are read by kernels enqueued on the engine's stream (there is no copy at call time): leave
+ * them unchanged until a later call that waits for the engine has returned (crim_run does). */
 int crim_upload_device(crim_t* h, int first, int count, const void* d_bgr, const void* d_mask);
 
 /* Page-locked host memory (hipHostMalloc / hipHostFree): uploads from and downloads into it are
